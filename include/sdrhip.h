@@ -1,0 +1,191 @@
+/*
+ * sdrhip.h -- C ABI of libsdrhip.so: the MI355X (gfx950) engine behind sdrdaemon's
+ * data-parallel hot path (integer half-band decimators / interpolators and the CM256
+ * Cauchy-MDS GF(256) block-erasure code).
+ *
+ * This is the drop-in boundary.  Every entry point states the reference interface it
+ * replaces (file:line relative to the f4exb/sdrdaemon tree).  Plain pointers and sizes
+ * only; no C++ or torch types.  All functions return 0 on success or a negative
+ * SDRHIP_E* code; sdrhip_last_error() gives the message of the calling thread's last
+ * failure.
+ *
+ * Threading: a handle is single-threaded; different handles may be used concurrently.
+ * Memory: every data pointer is either host memory (SDRHIP_MEM_HOST: the library
+ * stages it through pinned buffers and copies back, synchronously) or device memory on
+ * the context's GPU (SDRHIP_MEM_DEVICE: 16-byte aligned, work is enqueued on the
+ * context's HIP stream and NOT synchronised -- call sdrhip_ctx_synchronize()).
+ * IQ samples are interleaved little-endian {int16 re, int16 im} = IQSample
+ * (SDRDaemon.h:52-70); sample counts are in IQ samples, not int16 words.
+ */
+#ifndef SDRHIP_H
+#define SDRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDRHIP_OK 0
+#define SDRHIP_EINVAL (-1)   /* bad argument */
+#define SDRHIP_ENOMEM (-2)   /* host or device allocation failed */
+#define SDRHIP_EDEVICE (-3)  /* HIP runtime error (no GPU, launch failure ...) */
+#define SDRHIP_EALIGN (-4)   /* device pointer / stride not 16-byte aligned */
+#define SDRHIP_EDECODE (-5)  /* cm256 decode: duplicate original index / singular system */
+
+#define SDRHIP_MEM_HOST 0
+#define SDRHIP_MEM_DEVICE 1
+
+/* Downsampler::fcPos_t, Downsampler.h:29-33 */
+#define SDRHIP_FC_INF 0
+#define SDRHIP_FC_SUP 1
+#define SDRHIP_FC_CEN 2
+
+/* IntHalfbandFilterEO1 (x86 USE_SSE4_1 builds, centre tap x << 13, EO1.h:136-142) versus
+ * IntHalfbandFilterDB (all other builds, (x + 1) << 13, DB.h:102-103): Decimators.h:24-28 */
+#define SDRHIP_HB_EO1 0
+#define SDRHIP_HB_DB 1
+
+/* frame geometry, UDPSinkFEC.h:56-59,109 */
+#define SDRHIP_UDPSIZE 512
+#define SDRHIP_NB_ORIGINAL 128
+#define SDRHIP_BLOCK_BYTES 508
+#define SDRHIP_SAMPLES_PER_BLOCK 127
+#define SDRHIP_SAMPLES_PER_FRAME 16129
+
+const char *sdrhip_last_error(void);
+/* number of visible HIP devices (0 without a GPU; never fails) */
+int sdrhip_device_count(void);
+
+/* ------------------------------------------------------------------ context -- */
+/* One per GPU and host thread of control.  hip_stream: a hipStream_t to enqueue on
+ * (e.g. torch.cuda.current_stream().cuda_stream), or NULL for the device's null stream. */
+typedef struct sdrhip_ctx sdrhip_ctx;
+int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out);
+void sdrhip_ctx_destroy(sdrhip_ctx *ctx);
+int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
+/* Average duration in milliseconds of the kernels launched between timing_begin and
+ * timing_end on the context's stream, measured with hipEvents on that stream (what
+ * bench.py's roofline object reports). */
+int sdrhip_ctx_timing_begin(sdrhip_ctx *ctx);
+int sdrhip_ctx_timing_end(sdrhip_ctx *ctx, float *elapsed_ms);
+
+/* --------------------------------------------------------------- decimators -- */
+/* A bank of `nstreams` independent `Decimators` objects (Decimators.h:32-71): per stream
+ * the six half-band filter states m_decimator2..64 persist across calls, exactly like the
+ * reference members.  hb_variant selects EO1 / DB rounding. */
+typedef struct sdrhip_decimators sdrhip_decimators;
+int sdrhip_decimators_create(sdrhip_ctx *ctx, int nstreams, int hb_variant, sdrhip_decimators **out);
+void sdrhip_decimators_destroy(sdrhip_decimators *d);
+int sdrhip_decimators_reset(sdrhip_decimators *d); /* back to the constructor's zero state */
+
+/* One Decimators::decimate<2^log2decim>_{inf,sup,cen}(sampleSize, in, out) call
+ * (Decimators.h:35-53; dispatch of Downsampler::process, Downsampler.cpp:74-162) on each
+ * stream of the bank.  log2decim 0..6 (0 = Downsampler's copy + decimate1 rescale,
+ * Decimators.cpp:22-35), fcpos SDRHIP_FC_*.  Stream s reads n_in samples at
+ * iq_in + 2*s*in_stride and writes *n_out = n_in >> log2decim samples (what the reference
+ * resizes `out` to) at iq_out + 2*s*out_stride (strides in samples; ignored for one
+ * stream).  *sampleSize (effective bits, 8..16) is updated as the reference's by-reference
+ * argument.  As in the reference, floor(n_in / N) * N samples are consumed and the
+ * remainder never enters the filter history. */
+int sdrhip_decimate(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *iq_in,
+                    size_t n_in, size_t in_stride, int16_t *iq_out, size_t out_stride, size_t *n_out, int mem);
+
+/* ------------------------------------------------------------ interpolators -- */
+/* Bank of `Interpolators` objects (Interpolators.h:35-61): HB64, HB32, 4 x HB16 states. */
+typedef struct sdrhip_interpolators sdrhip_interpolators;
+int sdrhip_interpolators_create(sdrhip_ctx *ctx, int nstreams, sdrhip_interpolators **out);
+void sdrhip_interpolators_destroy(sdrhip_interpolators *p);
+int sdrhip_interpolators_reset(sdrhip_interpolators *p);
+/* One Interpolators::interpolate<2^log2interp>_cen(in, out) call per stream
+ * (Interpolators.h:38-43; Upsampler::process, Upsampler.cpp:52-84; log2interp 0 copies).
+ * *n_out = n_in << log2interp.  log2interp = 6 reproduces the reference's
+ * interpolate64_cen as it is (32 interpolated + 32 zero samples per input,
+ * Interpolators.cpp:363-606). */
+int sdrhip_interpolate(sdrhip_interpolators *p, int log2interp, const int16_t *iq_in, size_t n_in,
+                       size_t in_stride, int16_t *iq_out, size_t out_stride, size_t *n_out, int mem);
+
+/* -------------------------------------------------------------------- CM256 -- */
+/* CM256::cm256_encoder_params / CM256::cm256_block as used at UDPSinkFEC.cpp:195-246 and
+ * SDRdaemonFECBuffer.cpp:148-197 (layout-compatible with cm256cc's structs). */
+typedef struct {
+    int OriginalCount;
+    int RecoveryCount;
+    int BlockBytes;
+} sdrhip_cm256_params;
+typedef struct {
+    void *Block;
+    unsigned char Index;
+} sdrhip_cm256_block;
+
+/* CM256::cm256_encode(params, originals, recoveryBlocks) (UDPSinkFEC.cpp:246): host
+ * pointers; originals taken positionally; recovery block r is Cauchy row OriginalCount + r. */
+int sdrhip_cm256_encode(sdrhip_ctx *ctx, sdrhip_cm256_params params, const sdrhip_cm256_block *originals,
+                        void *recoveryBlocks);
+/* CM256::cm256_decode(params, blocks) (SDRdaemonFECBuffer.cpp:197): host pointers, in-place
+ * contract of the library: recovered originals overwrite the recovery blocks' buffers and
+ * their Index becomes the recovered original's index.  RecoveryCount == 1 takes the
+ * library's XOR shortcut (see DESIGN.md "mirrored quirks"). */
+int sdrhip_cm256_decode(sdrhip_ctx *ctx, sdrhip_cm256_params params, sdrhip_cm256_block *blocks);
+
+/* Batched form of the encode section of UDPSinkFEC::transmitUDP (UDPSinkFEC.cpp:228-256):
+ * frames = nframes x 128 super blocks of 512 bytes (header + 508 protected bytes);
+ * recovery_out = nframes x nb_fec super blocks with header {frameIndex, 128 + r, 0}. */
+int sdrhip_fec_encode_frames(sdrhip_ctx *ctx, const uint8_t *frames, size_t nframes, int nb_fec,
+                             uint8_t *recovery_out, int mem);
+/* Batched form of the decode section of SDRdaemonFECBuffer::writeAndRead
+ * (SDRdaemonFECBuffer.cpp:143-213) + getSlotData (:72-75): rx = nframes x 128 super
+ * blocks, the first 128 datagrams of each frame in arrival order (originals and recovery
+ * mixed; the reference relies on recovery blocks arriving last, :210); payload_out =
+ * nframes x 127 x 508 bytes (blocks 1..127 in place, i.e. 16129 IQ samples per frame);
+ * block0_out (may be NULL) = nframes x 508 bytes (the meta block).  rx is always host
+ * memory for the headers' sake when mem == SDRHIP_MEM_HOST; with SDRHIP_MEM_DEVICE the
+ * block indices are passed separately in `indices` (nframes x 128 bytes, host). */
+int sdrhip_fec_decode_frames(sdrhip_ctx *ctx, const uint8_t *rx, const uint8_t *indices, size_t nframes,
+                             uint8_t *payload_out, uint8_t *block0_out, int mem);
+
+/* ------------------------------------------------------------ fused Rx pipe -- */
+/* Bank of Rx chains: Downsampler::process (Downsampler.cpp:74-162) -> UDPSinkFEC::write
+ * framing (UDPSinkFEC.cpp:79-191) -> encode section of transmitUDP (:228-256), i.e. what
+ * sdrdaemonrx's main loop + writer + tx threads compute between source_buffer.pull() and
+ * sendto() (sdrdaemonrx.cpp:579-663). */
+typedef struct {
+    int log2decim;                 /* decim=  0..6 */
+    int fcpos;                     /* fcpos=  0..2 */
+    int hb_variant;                /* SDRHIP_HB_EO1 / SDRHIP_HB_DB */
+    unsigned sample_bits;          /* DeviceSource::get_sample_bits(), 8..16 */
+    int nb_fec;                    /* fecblk= 0..128 */
+    uint32_t center_frequency_khz; /* UDPSink::setCenterFrequency (kHz on the wire, UDPSink.h:93) */
+    uint32_t sample_rate;          /* rate AFTER decimation, UDPSink::setSampleRate */
+} sdrhip_rx_config;
+typedef struct sdrhip_rx sdrhip_rx;
+int sdrhip_rx_create(sdrhip_ctx *ctx, int nstreams, const sdrhip_rx_config *cfg, sdrhip_rx **out);
+void sdrhip_rx_destroy(sdrhip_rx *rx);
+/* Feeds n_in device-rate samples per stream.  Completed frames of stream s are written to
+ * frames_out + s*frame_stride_bytes as (128 + nb_fec) super blocks of 512 bytes each,
+ * frame after frame; *n_frames (per stream, identical for all streams) is the number of
+ * frames completed by this call.  tv_sec/tv_usec stamp the meta block of frames STARTED by
+ * this call (the reference calls gettimeofday there, UDPSinkFEC.cpp:91).  frames_out must
+ * hold sdrhip_rx_max_frames(rx, n_in) frames per stream. */
+int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in, size_t in_stride, uint32_t tv_sec,
+                      uint32_t tv_usec, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames,
+                      int mem);
+size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in);
+
+/* ------------------------------------------------------------ fused Tx pipe -- */
+/* Bank of Tx chains: SDRdaemonFECBuffer decode (SDRdaemonFECBuffer.cpp:143-213) ->
+ * getSlotData (:72-75) -> Upsampler::process (Upsampler.cpp:52-84), i.e. what
+ * sdrdaemontx's main loop computes between recvfrom() and sink_buffer.push()
+ * (sdrdaemontx.cpp:449-498).  rx = per stream nframes x 128 received super blocks (arrival
+ * order); iq_out receives nframes * 16129 << log2interp samples per stream. */
+typedef struct sdrhip_tx sdrhip_tx;
+int sdrhip_tx_create(sdrhip_ctx *ctx, int nstreams, int log2interp, sdrhip_tx **out);
+void sdrhip_tx_destroy(sdrhip_tx *tx);
+int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t *indices, size_t nframes,
+                      size_t rx_stride_bytes, int16_t *iq_out, size_t out_stride, size_t *n_out, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRHIP_H */

@@ -1,0 +1,207 @@
+// gf_kernels.hip -- GF(2^8) block arithmetic of CM256 for gfx950 (MI355X).
+//
+// Replaces the gf256_muladd_mem loops behind CM256::cm256_encode (UDPSinkFEC.cpp:246,
+// 31 x 128 multiply-adds + 128 XORs of 508 bytes per frame at 128+32) and
+// CM256::cm256_decode (SDRdaemonFECBuffer.cpp:197).  Both are one operation here:
+//     out[row] = XOR_col  coef[row][col] * in[col]        (508-byte blocks, bytes in GF(256))
+// with the encoder's Cauchy rows, or with the per-erasure-pattern decode matrix that
+// gf256.cpp derives on the host.
+//
+// Multiply by a wave-uniform constant m without MFMA and without per-byte gathers: the data
+// dword is split into three selector dwords (bits 0-2, 3-5, 6-7 of each byte; computed once
+// per data dword and reused by every row) and the product is three v_perm_b32 byte-table
+// lookups into the 8+8+4 byte tables of m, XOR-ed together (GF multiplication by a constant
+// is GF(2)-linear).  The 32-byte table of each of the 256 constants lives in LDS and is
+// fetched with uniform-address ds_read_b128/b32 (broadcast), the coefficients of the
+// workgroup's rows sit next to it.  A lane owns 2 x 16 bytes (two frames) of a block column
+// slab, a wave 4 frames x 1 block, and accumulates 8 rows at a time in registers.
+#include "sdrhip_internal.h"
+
+namespace sdrhip {
+namespace {
+
+constexpr int GF_NT = 256;
+constexpr int RB = 8;         // rows accumulated per wave pass
+constexpr int ROWS_PER_WG = 32;
+constexpr int FRAMES_PER_WG = 4;
+
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+
+struct Sel { unsigned a, b, c; };
+
+__device__ __forceinline__ Sel make_sel(unsigned x)
+{
+    Sel s;
+    s.a = x & 0x07070707u;
+    s.b = (x >> 3) & 0x07070707u;
+    s.c = (x >> 6) & 0x03030303u;
+    return s;
+}
+
+// product of the four bytes of the data dword (given as selectors) with the constant whose
+// tables are (ta_lo, ta_hi | tb_lo, tb_hi | tc)
+__device__ __forceinline__ unsigned mulc(const Sel &s, const uint4_t &t, unsigned tc)
+{
+    unsigned pa = __builtin_amdgcn_perm(t.y, t.x, s.a);
+    unsigned pb = __builtin_amdgcn_perm(t.w, t.z, s.b);
+    unsigned pc = __builtin_amdgcn_perm(0u, tc, s.c);
+    return pa ^ pb ^ pc;
+}
+
+__device__ __forceinline__ uint4_t load_slab(const uint8_t *p, int l)
+{
+    // 16 bytes at p + 16 l of a 508-byte block; the last lane's slab is 12 bytes
+    const unsigned *q = reinterpret_cast<const unsigned *>(p) + 4 * l;
+    uint4_t v;
+    v.x = q[0]; v.y = q[1]; v.z = q[2];
+    v.w = (l < 31) ? q[3] : 0u;
+    return v;
+}
+
+__device__ __forceinline__ void store_slab(uint8_t *p, int l, const uint4_t &v)
+{
+    unsigned *q = reinterpret_cast<unsigned *>(p) + 4 * l;
+    q[0] = v.x; q[1] = v.y; q[2] = v.z;
+    if (l < 31) q[3] = v.w;
+}
+
+__global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned tab[256 * 8];              // 8 KB
+    __shared__ __attribute__((aligned(16))) uint8_t coef[ROWS_PER_WG * 256];    // rows x cols (cols <= 256)
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int h = lane >> 5, l = lane & 31;
+    const int group = blockIdx.x;
+    const int row0 = blockIdx.y * ROWS_PER_WG;
+
+    // frames of this group (all share one coefficient matrix)
+    int fr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int slot = h * 2 + u;
+        int f = a.frame_list ? a.frame_list[group * FRAMES_PER_WG + slot] : group * FRAMES_PER_WG + slot;
+        fr[u] = (f >= 0 && f < a.nframes) ? f : -1;
+    }
+    const int cm = a.coef_per_frame ? group : 0;
+    const int cols = a.cols;
+
+    for (int i = tid; i < 256 * 8; i += GF_NT) tab[i] = reinterpret_cast<const unsigned *>(a.tab)[i];
+    {
+        const uint8_t *cg = a.coef + ((size_t)cm * a.rows + row0) * cols;
+        const int nrows = (a.rows - row0) < ROWS_PER_WG ? (a.rows - row0) : ROWS_PER_WG;
+        for (int i = tid; i < ROWS_PER_WG * cols; i += GF_NT) {
+            int r = i / cols;
+            coef[r * 256 + (i - r * cols)] = (r < nrows) ? cg[i] : 0;
+        }
+    }
+    __syncthreads();
+
+    const int r0 = wave * RB; // this wave's rows inside the workgroup tile
+    if (row0 + r0 >= a.rows) return;
+
+    uint4_t acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[rb][u] = (uint4_t){0u, 0u, 0u, 0u};
+
+    const int16_t *csrc = a.col_src ? a.col_src + (size_t)cm * cols : nullptr;
+    for (int j = 0; j < cols; ++j) {
+        const int sb = csrc ? csrc[j] : j;
+        Sel s[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            uint4_t x = (uint4_t){0u, 0u, 0u, 0u};
+            if (fr[u] >= 0 && sb >= 0) x = load_slab(a.in + (size_t)fr[u] * a.in_frame_bytes + (size_t)sb * a.in_pitch + a.in_off, l);
+            s[u][0] = make_sel(x.x); s[u][1] = make_sel(x.y); s[u][2] = make_sel(x.z); s[u][3] = make_sel(x.w);
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const unsigned m = coef[(r0 + rb) * 256 + j];
+            const uint4_t t = *reinterpret_cast<const uint4_t *>(&tab[m * 8]);
+            const unsigned tc = tab[m * 8 + 4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                acc[rb][u].x ^= mulc(s[u][0], t, tc);
+                acc[rb][u].y ^= mulc(s[u][1], t, tc);
+                acc[rb][u].z ^= mulc(s[u][2], t, tc);
+                acc[rb][u].w ^= mulc(s[u][3], t, tc);
+            }
+        }
+    }
+
+    const int16_t *rdst = a.row_dst ? a.row_dst + (size_t)cm * a.rows : nullptr;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r = row0 + r0 + rb;
+        if (r >= a.rows) break;
+        const int db = rdst ? rdst[r] : r;
+        if (db < 0) continue;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (fr[u] >= 0) store_slab(a.out + (size_t)fr[u] * a.out_frame_bytes + (size_t)db * a.out_pitch + a.out_off, l, acc[rb][u]);
+    }
+}
+
+// scatter copy of 508-byte blocks: dst[f][map[f][p]] = src[f][p] for map >= 0
+__global__ void block_scatter_kernel(const uint8_t *src, size_t src_frame_bytes, int src_pitch, int src_off, uint8_t *dst,
+                                     size_t dst_frame_bytes, int dst_pitch, int dst_off, const int16_t *map, int nblocks,
+                                     int nframes)
+{
+    const int f = blockIdx.y;
+    const int p = blockIdx.x * (blockDim.x / 32) + (threadIdx.x >> 5);
+    const int l = threadIdx.x & 31;
+    if (f >= nframes || p >= nblocks) return;
+    const int d = map[(size_t)f * nblocks + p];
+    if (d < 0) return;
+    uint4_t v = load_slab(src + (size_t)f * src_frame_bytes + (size_t)p * src_pitch + src_off, l);
+    store_slab(dst + (size_t)f * dst_frame_bytes + (size_t)d * dst_pitch + dst_off, l, v);
+}
+
+// headers of the recovery super blocks: {frameIndex (from block 0 of the frame), 128 + r, 0}
+__global__ void fec_header_kernel(const uint8_t *frames, size_t in_frame_bytes, uint8_t *rec, size_t out_frame_bytes, int nb_fec,
+                                  int first_index, int nframes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nframes * nb_fec) return;
+    const int f = i / nb_fec, r = i - f * nb_fec;
+    const unsigned h0 = *reinterpret_cast<const unsigned *>(frames + (size_t)f * in_frame_bytes);
+    *reinterpret_cast<unsigned *>(rec + (size_t)f * out_frame_bytes + (size_t)r * 512) = (h0 & 0xffffu) | ((unsigned)(first_index + r) << 16);
+}
+
+} // namespace
+
+hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream)
+{
+    if (a.nframes <= 0 || a.rows <= 0) return hipSuccess;
+    const int ngroups = a.frame_list ? a.ngroups : (a.nframes + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
+    if (ngroups <= 0) return hipSuccess;
+    dim3 grid(ngroups, (a.rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
+    hipLaunchKernelGGL(gf_apply_kernel, grid, dim3(GF_NT), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_block_scatter(const uint8_t *src, size_t src_frame_bytes, int src_pitch, int src_off, uint8_t *dst,
+                                size_t dst_frame_bytes, int dst_pitch, int dst_off, const int16_t *map, int nblocks, int nframes,
+                                hipStream_t stream)
+{
+    if (nframes <= 0) return hipSuccess;
+    dim3 grid((nblocks + 7) / 8, nframes);
+    hipLaunchKernelGGL(block_scatter_kernel, grid, dim3(256), 0, stream, src, src_frame_bytes, src_pitch, src_off, dst,
+                       dst_frame_bytes, dst_pitch, dst_off, map, nblocks, nframes);
+    return hipGetLastError();
+}
+
+hipError_t launch_fec_headers(const uint8_t *frames, size_t in_frame_bytes, uint8_t *rec, size_t out_frame_bytes, int nb_fec,
+                              int first_index, int nframes, hipStream_t stream)
+{
+    if (nframes <= 0 || nb_fec <= 0) return hipSuccess;
+    int n = nframes * nb_fec;
+    hipLaunchKernelGGL(fec_header_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, frames, in_frame_bytes, rec, out_frame_bytes,
+                       nb_fec, first_index, nframes);
+    return hipGetLastError();
+}
+
+} // namespace sdrhip

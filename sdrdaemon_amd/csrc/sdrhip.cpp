@@ -1,0 +1,263 @@
+// sdrhip.cpp -- host side of libsdrhip.so: the C ABI declared in include/sdrhip.h.
+// C++11-style host code calling HIP; no torch, no oracle, no CPU fallback: without a
+// usable GPU every compute entry point fails with SDRHIP_EDEVICE.
+#include "sdrhip_host.h"
+#include "gf256.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace sdrhip;
+
+namespace {
+thread_local std::string g_err;
+}
+
+namespace sdrhip {
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int DevBuf::reserve(size_t n)
+{
+    if (n <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 4 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return fail(SDRHIP_ENOMEM, "hipMalloc(%zu) failed", want); }
+    cap = want;
+    return 0;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+} // namespace sdrhip
+
+extern "C" const char *sdrhip_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sdrhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
+{
+    if (!out) return fail(SDRHIP_EINVAL, "ctx_create: out is NULL");
+    *out = nullptr;
+    int n = sdrhip_device_count();
+    if (n <= 0) return fail(SDRHIP_EDEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(SDRHIP_EINVAL, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    sdrhip_ctx *c = new (std::nothrow) sdrhip_ctx();
+    if (!c) return fail(SDRHIP_ENOMEM, "out of host memory");
+    c->device = device;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    std::vector<uint8_t> tab(256 * 32);
+    gf_build_tables(tab.data());
+    if (hipMalloc(reinterpret_cast<void **>(&c->gf_tab), tab.size()) != hipSuccess) { delete c; return fail(SDRHIP_ENOMEM, "hipMalloc gf tables"); }
+    if (hipMemcpy(c->gf_tab, tab.data(), tab.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(c->gf_tab); delete c; return fail(SDRHIP_EDEVICE, "upload gf tables"); }
+    std::vector<uint8_t> em(128 * 128);
+    cm256_encode_matrix(128, 128, em.data());
+    if (hipMalloc(reinterpret_cast<void **>(&c->enc_matrix), em.size()) != hipSuccess ||
+        hipMemcpy(c->enc_matrix, em.data(), em.size(), hipMemcpyHostToDevice) != hipSuccess) { delete c; return fail(SDRHIP_ENOMEM, "upload encode matrix"); }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
+    *out = c;
+    return SDRHIP_OK;
+}
+
+extern "C" void sdrhip_ctx_destroy(sdrhip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->in.release(); c->out.release(); c->aux.release(); c->aux2.release(); c->aux3.release();
+    if (c->gf_tab) (void)hipFree(c->gf_tab);
+    if (c->enc_matrix) (void)hipFree(c->enc_matrix);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+extern "C" int sdrhip_ctx_synchronize(sdrhip_ctx *c)
+{
+    if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDRHIP_OK;
+}
+
+extern "C" int sdrhip_ctx_timing_begin(sdrhip_ctx *c)
+{
+    if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return SDRHIP_OK;
+}
+
+extern "C" int sdrhip_ctx_timing_end(sdrhip_ctx *c, float *ms)
+{
+    if (!c || !ms) return fail(SDRHIP_EINVAL, "ctx/ms is NULL");
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return SDRHIP_OK;
+}
+
+// ------------------------------------------------------------------------------ decimators
+struct sdrhip_decimators {
+    sdrhip_ctx *ctx;
+    int nstreams;
+    int bias;
+    int32_t *state[2]; // double buffered [nstreams][DEC_STATE_WORDS]
+    int cur;
+    bool stage0_int16; // history of m_decimator2 fits int16 (it last saw raw samples or nothing)
+};
+
+extern "C" int sdrhip_decimators_create(sdrhip_ctx *ctx, int nstreams, int hb_variant, sdrhip_decimators **out)
+{
+    if (!ctx || !out || nstreams <= 0 || nstreams > 65535) return fail(SDRHIP_EINVAL, "decimators_create: bad argument");
+    if (hb_variant != SDRHIP_HB_EO1 && hb_variant != SDRHIP_HB_DB) return fail(SDRHIP_EINVAL, "hb_variant must be SDRHIP_HB_EO1 or SDRHIP_HB_DB");
+    HIP_TRY(hipSetDevice(ctx->device));
+    sdrhip_decimators *d = new (std::nothrow) sdrhip_decimators();
+    if (!d) return fail(SDRHIP_ENOMEM, "out of host memory");
+    d->ctx = ctx; d->nstreams = nstreams; d->bias = hb_variant; d->cur = 0; d->stage0_int16 = true;
+    size_t bytes = (size_t)nstreams * DEC_STATE_WORDS * sizeof(int32_t);
+    d->state[0] = d->state[1] = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d->state[0]), bytes) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&d->state[1]), bytes) != hipSuccess) {
+        if (d->state[0]) (void)hipFree(d->state[0]);
+        delete d;
+        return fail(SDRHIP_ENOMEM, "hipMalloc decimator state");
+    }
+    *out = d;
+    return sdrhip_decimators_reset(d);
+}
+
+extern "C" void sdrhip_decimators_destroy(sdrhip_decimators *d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipStreamSynchronize(d->ctx->stream);
+    (void)hipFree(d->state[0]);
+    (void)hipFree(d->state[1]);
+    delete d;
+}
+
+extern "C" int sdrhip_decimators_reset(sdrhip_decimators *d)
+{
+    if (!d) return fail(SDRHIP_EINVAL, "decimators is NULL");
+    size_t bytes = (size_t)d->nstreams * DEC_STATE_WORDS * sizeof(int32_t);
+    HIP_TRY(hipMemsetAsync(d->state[0], 0, bytes, d->ctx->stream)); // ctor zero fill, EO1.h:171-188
+    HIP_TRY(hipMemsetAsync(d->state[1], 0, bytes, d->ctx->stream));
+    d->cur = 0;
+    d->stage0_int16 = true;
+    return SDRHIP_OK;
+}
+
+namespace sdrhip {
+// device-pointer core shared with the fused Rx pipe; frame_* = 0 for plain output
+int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in,
+                    size_t n_in, size_t in_stride, int16_t *out, size_t out_stride, size_t *n_out, int frame_mode,
+                    int frame_blocks, uint64_t frame_sample_base)
+{
+    sdrhip_ctx *c = d->ctx;
+    const unsigned L = (unsigned)log2decim;
+    const unsigned ss = *sampleSize;
+    if (L == 0) {
+        // Downsampler::process m_decim == 0: copy + decimate1 (Downsampler.cpp:76-80, Decimators.cpp:22-35)
+        if (n_out) *n_out = n_in;
+        if (n_in == 0) return SDRHIP_OK;
+        if (frame_mode) return fail(SDRHIP_EINVAL, "internal: frame mode needs log2decim >= 1");
+        int norm = ss < 16 ? (int)(16 - ss) : 0;
+        hipError_t e = launch_decimate_simple(0, fcpos, in, in_stride, out, out_stride, n_in, d->nstreams, norm, 0, c->stream);
+        if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "decimate1 launch: %s", hipGetErrorString(e));
+        return SDRHIP_OK;
+    }
+    const unsigned target = 16 - L; // Decimators.cpp:43-44, 132-133, 222-223 ...
+    const unsigned trunk = ss < target ? 0 : ss - target;
+    const unsigned norm = ss < target ? target - ss : 0;
+    const size_t n_resize = n_in >> L; // out.resize(len / N)
+    *sampleSize = ss + L - trunk;
+    if (n_out) *n_out = n_resize;
+    if (n_resize == 0) return SDRHIP_OK; // (the reference's unsigned loop bound would wrap here)
+
+    if (fcpos != SDRHIP_FC_CEN && L <= 2) {
+        if (frame_mode) return fail(SDRHIP_EINVAL, "internal: frame mode unsupported for filter-less decimation");
+        hipError_t e = launch_decimate_simple((int)L, fcpos, in, in_stride, out, out_stride, n_in, d->nstreams, (int)norm, (int)trunk, c->stream);
+        if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "decimate%u launch: %s", 1u << L, hipGetErrorString(e));
+        return SDRHIP_OK;
+    }
+
+    DecimArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.in_stride = in_stride; a.out_stride = out_stride;
+    a.n_used = n_resize << L;
+    a.state_cur = d->state[d->cur]; a.state_next = d->state[d->cur ^ 1];
+    a.nstreams = d->nstreams;
+    a.bias = d->bias; a.norm = (int)norm; a.trunk = (int)trunk;
+    a.frame_mode = frame_mode; a.frame_blocks = frame_blocks; a.frame_sample_base = frame_sample_base;
+    plan_decimate((int)L, fcpos, a.n_used, d->nstreams, &a.nsub_per_seg, &a.nseg);
+    const bool cen = (fcpos == SDRHIP_FC_CEN);
+    const bool pack16 = cen && d->stage0_int16;
+    hipError_t e = launch_decimate((int)L, fcpos, pack16, a, c->stream);
+    if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "decimate launch: %s", hipGetErrorString(e));
+    d->cur ^= 1;
+    d->stage0_int16 = cen; // m_decimator2 now holds raw int16 samples (cen) or rotate-sums (inf/sup)
+    return SDRHIP_OK;
+}
+} // namespace sdrhip
+
+extern "C" int sdrhip_decimate(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *iq_in,
+                               size_t n_in, size_t in_stride, int16_t *iq_out, size_t out_stride, size_t *n_out, int mem)
+{
+    if (!d || !sampleSize) return fail(SDRHIP_EINVAL, "decimate: NULL handle or sampleSize");
+    if (log2decim < 0 || log2decim > 6) return fail(SDRHIP_EINVAL, "Invalid log2 decimation factor"); // Downsampler.cpp:39-43
+    if (fcpos < SDRHIP_FC_INF || fcpos > SDRHIP_FC_CEN) return fail(SDRHIP_EINVAL, "Invalid Fc position index"); // :55-59
+    if (*sampleSize < 1 || *sampleSize > 16) return fail(SDRHIP_EINVAL, "sampleSize must be 1..16");
+    if (n_in && (!iq_in || !iq_out)) return fail(SDRHIP_EINVAL, "decimate: NULL buffer");
+    sdrhip_ctx *c = d->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int S = d->nstreams;
+    const size_t n_res = n_in >> log2decim;
+    if (S == 1) { in_stride = n_in; out_stride = n_res; }
+    if (S > 1 && (in_stride < n_in || out_stride < n_res)) return fail(SDRHIP_EINVAL, "decimate: stride smaller than the per-stream length");
+
+    if (mem == SDRHIP_MEM_DEVICE) {
+        if (n_in && (!aligned16(iq_in) || !aligned16(iq_out) || (S > 1 && ((in_stride & 3) || (out_stride & 3)))))
+            return fail(SDRHIP_EALIGN, "decimate: device pointers must be 16-byte aligned and strides multiples of 4 samples");
+        return decimate_device(d, log2decim, fcpos, sampleSize, iq_in, n_in, in_stride, iq_out, out_stride, n_out, 0, 0, 0);
+    }
+    if (mem != SDRHIP_MEM_HOST) return fail(SDRHIP_EINVAL, "mem must be SDRHIP_MEM_HOST or SDRHIP_MEM_DEVICE");
+
+    // host buffers: stage through device memory with padded (16-byte aligned) per-stream strides
+    const size_t dis = (n_in + 3) & ~(size_t)3, dos = (n_res + 3) & ~(size_t)3;
+    if (n_in == 0) { if (n_out) *n_out = 0; return SDRHIP_OK; }
+    int rc;
+    if ((rc = c->in.reserve((size_t)S * dis * 4 + 16))) return rc;
+    if ((rc = c->out.reserve((size_t)S * dos * 4 + 16))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(c->in.p, dis * 4, iq_in, in_stride * 4, n_in * 4, S, hipMemcpyHostToDevice, c->stream));
+    rc = decimate_device(d, log2decim, fcpos, sampleSize, static_cast<const int16_t *>(c->in.p), n_in, dis,
+                         static_cast<int16_t *>(c->out.p), dos, n_out, 0, 0, 0);
+    if (rc) return rc;
+    if (n_res) HIP_TRY(hipMemcpy2DAsync(iq_out, out_stride * 4, c->out.p, dos * 4, n_res * 4, S, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDRHIP_OK;
+}

@@ -1,0 +1,53 @@
+// sdrhip_host.h -- host-side internals shared by the .cpp files of libsdrhip.so
+#pragma once
+#include "../../include/sdrhip.h"
+#include "sdrhip_internal.h"
+
+#include <cstdint>
+#include <string>
+
+namespace sdrhip {
+
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                                           \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) return ::sdrhip::fail(SDRHIP_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+// growable device scratch buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n);
+    void release();
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// device-pointer cores (no argument validation, no staging)
+int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in, size_t n_in,
+                    size_t in_stride, int16_t *out, size_t out_stride, size_t *n_out, int frame_mode, int frame_blocks,
+                    uint64_t frame_sample_base);
+int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *in, size_t n_in, size_t in_stride, int16_t *out,
+                       size_t out_stride, size_t *n_out);
+// frames/recovery on the device; recovery slots may be interleaved with the frames
+// (rec_frame_bytes = stride between the recovery areas of consecutive frames)
+int fec_encode_device(sdrhip_ctx *ctx, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
+                      size_t rec_frame_bytes);
+// rx on the device, indices on the host; payload_out / block0_out on the device
+int fec_decode_device(sdrhip_ctx *ctx, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
+                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out);
+
+} // namespace sdrhip
+
+struct sdrhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    sdrhip::DevBuf in, out, aux, aux2, aux3; // staging for SDRHIP_MEM_HOST calls and FEC work areas
+    uint8_t *gf_tab = nullptr;               // 256 x 32 B multiplier tables (device)
+    uint8_t *enc_matrix = nullptr;           // 128 x 128 encode matrix, rows 128..255 (device)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};

@@ -1,0 +1,96 @@
+// sdrhip_internal.h -- shared between the host side (sdrhip.cpp) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace sdrhip {
+
+// Per-stream half-band decimator state: for each of the six filter instances
+// (m_decimator2..64, Decimators.h:56-70) the last 64 inputs, split the way the kernels
+// consume them: plane p = comp * 2 + parity (comp 0 = I, 1 = Q; parity 0 = even input
+// = first sample of a myDecimate pair, 1 = odd), 32 int32 entries each, oldest first.
+constexpr int DEC_STAGES = 6;
+constexpr int DEC_HIST = 32;
+constexpr int DEC_STATE_WORDS = DEC_STAGES * 4 * DEC_HIST; // int32 words per stream
+
+// Per-stream interpolator state: for each of the six instances (m_interpolator2..64,
+// Interpolators.h:47-52) the last 32 inputs per component (ring of order/2 <= 32), oldest first.
+constexpr int INT_STAGES = 6;
+constexpr int INT_HIST = 32;
+constexpr int INT_STATE_WORDS = INT_STAGES * 2 * INT_HIST;
+
+struct DecimArgs {
+    const int16_t *in;   // stream s at in + 2 * s * in_stride
+    int16_t *out;        // stream s at out + 2 * s * out_stride (or frame layout, see frame_*)
+    size_t in_stride;    // samples
+    size_t out_stride;   // samples
+    size_t n_used;       // raw samples consumed per stream (multiple of 2^log2decim)
+    const int32_t *state_cur; // [nstreams][DEC_STATE_WORDS]
+    int32_t *state_next;
+    int nstreams;
+    int nsub_per_seg;    // sub-chunks per segment
+    int nseg;            // grid.x
+    int bias;            // 0 EO1, 1 DB
+    int norm, trunk;     // final `<< norm >> trunk`
+    // frame-layout epilogue (fused Rx pipe): when frame_mode != 0 the decimated sample with
+    // per-stream running index g = out_index + frame_sample_base goes to the payload of super
+    // block 1 + (g % 16129) / 127 of frame g / 16129 (UDPSinkFEC.cpp:134-155); `out` then is a
+    // byte pointer to the stream's first frame slot and out_stride its stride in BYTES / 4.
+    int frame_mode;
+    int frame_blocks;        // super blocks per frame slot (128 + nb_fec)
+    uint64_t frame_sample_base; // samples already sitting in the first (partial) frame slot
+};
+
+// returns hipSuccess or the launch error
+hipError_t launch_decimate(int log2decim, int fcpos, bool pack16, const DecimArgs &a, hipStream_t stream);
+// picks nsub_per_seg / nseg for a call (host helper living next to the kernel's geometry)
+void plan_decimate(int log2decim, int fcpos, size_t n_used, int nstreams, int *nsub_per_seg, int *nseg);
+
+// filter-less paths: log2decim 0 (decimate1) and inf/sup 2, 4 (Decimators.cpp:22-91,127-170)
+hipError_t launch_decimate_simple(int log2decim, int fcpos, const int16_t *in, size_t in_stride, int16_t *out,
+                                  size_t out_stride, size_t n_in, int nstreams, int norm, int trunk,
+                                  hipStream_t stream);
+
+struct InterpArgs {
+    const int16_t *in;
+    int16_t *out;
+    size_t in_stride, out_stride; // samples
+    size_t n_in;                  // input samples per stream
+    const int32_t *state_cur;     // [nstreams][INT_STATE_WORDS]
+    int32_t *state_next;
+    int nstreams;
+    int nsub_per_seg, nseg;
+    // payload mode (fused Tx pipe): input sample i of a stream is read from the 127 x 508 byte
+    // payload layout directly (contiguous, so identical to linear) -- kept for symmetry
+};
+hipError_t launch_interpolate(int log2interp, const InterpArgs &a, hipStream_t stream);
+void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_seg, int *nseg);
+
+// GF(256) matrix apply: out[f][r][:] = XOR_j coef[f or 0][r][j] * in[f][src(j)][:]
+struct GfArgs {
+    const uint8_t *in;       // frames: [nframes][in_blocks][in_pitch] bytes
+    uint8_t *out;            // [nframes][rows][out_pitch]
+    const uint8_t *coef;     // [ngroups or 1][rows][cols]
+    const uint8_t *tab;      // 256 x 32 byte multiplier tables (device)
+    size_t in_frame_bytes, out_frame_bytes;
+    int in_pitch, out_pitch; // bytes between consecutive blocks
+    int in_off, out_off;     // byte offset of the 508 protected bytes inside a block slot
+    int rows, cols;
+    int coef_per_frame;      // 1: coef indexed by frame, 0: shared
+    const int16_t *row_dst;  // optional [ngroups or 1][rows] destination block index, -1 = skip (else r)
+    const int16_t *col_src;  // optional [ngroups or 1][cols] source block index (else j)
+    int nframes;
+    // frames are processed in groups of four that share one coefficient matrix (index =
+    // group when coef_per_frame, else 0): frame_list[group * 4 + slot] (or -1), NULL = identity
+    const int32_t *frame_list;
+    int ngroups;
+};
+hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream);
+hipError_t launch_block_scatter(const uint8_t *src, size_t src_frame_bytes, int src_pitch, int src_off, uint8_t *dst,
+                                size_t dst_frame_bytes, int dst_pitch, int dst_off, const int16_t *map, int nblocks, int nframes,
+                                hipStream_t stream);
+hipError_t launch_fec_headers(const uint8_t *frames, size_t in_frame_bytes, uint8_t *rec, size_t out_frame_bytes, int nb_fec,
+                              int first_index, int nframes, hipStream_t stream);
+
+} // namespace sdrhip

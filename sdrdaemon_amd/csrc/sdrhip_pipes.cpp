@@ -1,0 +1,361 @@
+// sdrhip_pipes.cpp -- interpolator bank and the fused Rx / Tx pipes of include/sdrhip.h.
+#include "gf256.h"
+#include "sdrhip_host.h"
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace sdrhip;
+
+// --------------------------------------------------------------------------- interpolators
+struct sdrhip_interpolators {
+    sdrhip_ctx *ctx;
+    int nstreams;
+    int32_t *state[2]; // [nstreams][INT_STATE_WORDS]
+    int cur;
+};
+
+extern "C" int sdrhip_interpolators_create(sdrhip_ctx *ctx, int nstreams, sdrhip_interpolators **out)
+{
+    if (!ctx || !out || nstreams <= 0 || nstreams > 65535) return fail(SDRHIP_EINVAL, "interpolators_create: bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    sdrhip_interpolators *p = new (std::nothrow) sdrhip_interpolators();
+    if (!p) return fail(SDRHIP_ENOMEM, "out of host memory");
+    p->ctx = ctx; p->nstreams = nstreams; p->cur = 0;
+    size_t bytes = (size_t)nstreams * INT_STATE_WORDS * sizeof(int32_t);
+    p->state[0] = p->state[1] = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p->state[0]), bytes) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&p->state[1]), bytes) != hipSuccess) {
+        if (p->state[0]) (void)hipFree(p->state[0]);
+        delete p;
+        return fail(SDRHIP_ENOMEM, "hipMalloc interpolator state");
+    }
+    *out = p;
+    return sdrhip_interpolators_reset(p);
+}
+
+extern "C" void sdrhip_interpolators_destroy(sdrhip_interpolators *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    (void)hipFree(p->state[0]);
+    (void)hipFree(p->state[1]);
+    delete p;
+}
+
+extern "C" int sdrhip_interpolators_reset(sdrhip_interpolators *p)
+{
+    if (!p) return fail(SDRHIP_EINVAL, "interpolators is NULL");
+    size_t bytes = (size_t)p->nstreams * INT_STATE_WORDS * sizeof(int32_t);
+    HIP_TRY(hipMemsetAsync(p->state[0], 0, bytes, p->ctx->stream));
+    HIP_TRY(hipMemsetAsync(p->state[1], 0, bytes, p->ctx->stream));
+    p->cur = 0;
+    return SDRHIP_OK;
+}
+
+namespace sdrhip {
+int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *in, size_t n_in, size_t in_stride, int16_t *out,
+                       size_t out_stride, size_t *n_out)
+{
+    sdrhip_ctx *c = p->ctx;
+    if (n_out) *n_out = n_in << log2interp;
+    if (n_in == 0) return SDRHIP_OK;
+    if (log2interp == 0) { // Upsampler::process m_interp == 0: samples_out = samples_in (Upsampler.cpp:54-57)
+        HIP_TRY(hipMemcpy2DAsync(out, out_stride * 4, in, in_stride * 4, n_in * 4, p->nstreams, hipMemcpyDeviceToDevice, c->stream));
+        return SDRHIP_OK;
+    }
+    InterpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.out = out; a.in_stride = in_stride; a.out_stride = out_stride; a.n_in = n_in;
+    a.state_cur = p->state[p->cur]; a.state_next = p->state[p->cur ^ 1];
+    a.nstreams = p->nstreams;
+    plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
+    hipError_t e = launch_interpolate(log2interp, a, c->stream);
+    if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "interpolate launch: %s", hipGetErrorString(e));
+    p->cur ^= 1;
+    return SDRHIP_OK;
+}
+} // namespace sdrhip
+
+extern "C" int sdrhip_interpolate(sdrhip_interpolators *p, int log2interp, const int16_t *iq_in, size_t n_in, size_t in_stride,
+                                  int16_t *iq_out, size_t out_stride, size_t *n_out, int mem)
+{
+    if (!p) return fail(SDRHIP_EINVAL, "interpolate: NULL handle");
+    if (log2interp < 0 || log2interp > 6) return fail(SDRHIP_EINVAL, "Invalid log2 interpolation factor"); // Upsampler.cpp:38-42
+    if (n_in && (!iq_in || !iq_out)) return fail(SDRHIP_EINVAL, "interpolate: NULL buffer");
+    sdrhip_ctx *c = p->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int S = p->nstreams;
+    const size_t n_res = n_in << log2interp;
+    if (S == 1) { in_stride = n_in; out_stride = n_res; }
+    if (S > 1 && (in_stride < n_in || out_stride < n_res)) return fail(SDRHIP_EINVAL, "interpolate: stride smaller than the per-stream length");
+    if (mem == SDRHIP_MEM_DEVICE) {
+        if (n_in && (!aligned16(iq_in) || !aligned16(iq_out) || (S > 1 && ((in_stride & 3) || (out_stride & 3)))))
+            return fail(SDRHIP_EALIGN, "interpolate: device pointers must be 16-byte aligned and strides multiples of 4 samples");
+        return interpolate_device(p, log2interp, iq_in, n_in, in_stride, iq_out, out_stride, n_out);
+    }
+    if (mem != SDRHIP_MEM_HOST) return fail(SDRHIP_EINVAL, "mem must be SDRHIP_MEM_HOST or SDRHIP_MEM_DEVICE");
+    if (n_in == 0) { if (n_out) *n_out = 0; return SDRHIP_OK; }
+    const size_t dis = (n_in + 3) & ~(size_t)3, dos = (n_res + 3) & ~(size_t)3;
+    int rc;
+    if ((rc = c->in.reserve((size_t)S * dis * 4 + 16))) return rc;
+    if ((rc = c->out.reserve((size_t)S * dos * 4 + 16))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(c->in.p, dis * 4, iq_in, in_stride * 4, n_in * 4, S, hipMemcpyHostToDevice, c->stream));
+    if ((rc = interpolate_device(p, log2interp, c->in.as<int16_t>(), n_in, dis, c->out.as<int16_t>(), dos, n_out))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(iq_out, out_stride * 4, c->out.p, dos * 4, n_res * 4, S, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDRHIP_OK;
+}
+
+// --------------------------------------------------------------------------- fused Rx pipe
+namespace sdrhip {
+hipError_t launch_frame_meta(uint8_t *work, size_t stream_bytes, int frame_blocks, int nstreams, int first_frame, int nframes,
+                             unsigned frame_count0, const uint8_t *meta24, hipStream_t stream);
+}
+
+struct sdrhip_rx {
+    sdrhip_ctx *ctx;
+    int nstreams;
+    sdrhip_rx_config cfg;
+    sdrhip_decimators *dec;
+    DevBuf work;              // [nstreams][cap_frames][128 + nb_fec][512]
+    size_t cap_frames;        // frame slots per stream in `work`
+    uint64_t pending_samples; // decimated samples sitting in slot 0 (the partial frame)
+    bool frame_open;          // slot 0 has its meta block (a frame was started)
+    uint16_t frame_count;     // m_frameCount of slot 0
+    DevBuf meta;              // 24-byte meta record (device)
+};
+
+extern "C" int sdrhip_rx_create(sdrhip_ctx *ctx, int nstreams, const sdrhip_rx_config *cfg, sdrhip_rx **out)
+{
+    if (!ctx || !cfg || !out || nstreams <= 0) return fail(SDRHIP_EINVAL, "rx_create: bad argument");
+    if (cfg->log2decim < 0 || cfg->log2decim > 6) return fail(SDRHIP_EINVAL, "Invalid log2 decimation factor");
+    if (cfg->fcpos < 0 || cfg->fcpos > 2) return fail(SDRHIP_EINVAL, "Invalid Fc position index");
+    if (cfg->nb_fec < 0 || cfg->nb_fec > 128) return fail(SDRHIP_EINVAL, "nb_fec must be 0..128");
+    if (cfg->sample_bits < 1 || cfg->sample_bits > 16) return fail(SDRHIP_EINVAL, "sample_bits must be 1..16");
+    if (cfg->log2decim == 0 || (cfg->fcpos != SDRHIP_FC_CEN && cfg->log2decim <= 2))
+        return fail(SDRHIP_EINVAL, "rx pipe: the filter-less settings (decim 0, inf/sup 1-2) are not fused; use sdrhip_decimate + sdrhip_fec_encode_frames");
+    sdrhip_rx *rx = new (std::nothrow) sdrhip_rx();
+    if (!rx) return fail(SDRHIP_ENOMEM, "out of host memory");
+    rx->ctx = ctx; rx->nstreams = nstreams; rx->cfg = *cfg; rx->dec = nullptr;
+    rx->cap_frames = 0; rx->pending_samples = 0; rx->frame_open = false; rx->frame_count = 0;
+    int rc = sdrhip_decimators_create(ctx, nstreams, cfg->hb_variant, &rx->dec);
+    if (rc) { delete rx; return rc; }
+    if ((rc = rx->meta.reserve(64))) { sdrhip_decimators_destroy(rx->dec); delete rx; return rc; }
+    *out = rx;
+    return SDRHIP_OK;
+}
+
+extern "C" void sdrhip_rx_destroy(sdrhip_rx *rx)
+{
+    if (!rx) return;
+    sdrhip_decimators_destroy(rx->dec);
+    rx->work.release();
+    rx->meta.release();
+    delete rx;
+}
+
+extern "C" size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in)
+{
+    if (!rx) return 0;
+    return (size_t)((rx->pending_samples + (n_in >> rx->cfg.log2decim)) / SDRHIP_SAMPLES_PER_FRAME);
+}
+
+extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in, size_t in_stride, uint32_t tv_sec, uint32_t tv_usec,
+                                 uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames, int mem)
+{
+    if (!rx) return fail(SDRHIP_EINVAL, "rx is NULL");
+    if (n_frames) *n_frames = 0;
+    if (n_in == 0) return SDRHIP_OK;
+    if (!iq_in) return fail(SDRHIP_EINVAL, "rx_process: NULL input");
+    sdrhip_ctx *c = rx->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int S = rx->nstreams, L = rx->cfg.log2decim, R = rx->cfg.nb_fec;
+    const int FB = SDRHIP_NB_ORIGINAL + R;
+    const size_t frame_bytes = (size_t)FB * SDRHIP_UDPSIZE;
+    const size_t n_dec = n_in >> L;
+    const uint64_t total = rx->pending_samples + n_dec;
+    const size_t done = (size_t)(total / SDRHIP_SAMPLES_PER_FRAME);
+    const uint64_t rest = total - (uint64_t)done * SDRHIP_SAMPLES_PER_FRAME;
+    if (S == 1) in_stride = n_in;
+    if (done && !frames_out) return fail(SDRHIP_EINVAL, "rx_process: NULL frames_out");
+    if (S > 1 && done && frame_stride_bytes < done * frame_bytes) return fail(SDRHIP_EINVAL, "rx_process: frame stride too small");
+
+    const int16_t *din = iq_in;
+    size_t dstride = in_stride;
+    int rc;
+    if (mem == SDRHIP_MEM_HOST) {
+        dstride = (n_in + 3) & ~(size_t)3;
+        if ((rc = c->in.reserve((size_t)S * dstride * 4 + 16))) return rc;
+        HIP_TRY(hipMemcpy2DAsync(c->in.p, dstride * 4, iq_in, in_stride * 4, n_in * 4, S, hipMemcpyHostToDevice, c->stream));
+        din = c->in.as<int16_t>();
+    } else if (mem == SDRHIP_MEM_DEVICE) {
+        if (!aligned16(iq_in) || (S > 1 && (in_stride & 3))) return fail(SDRHIP_EALIGN, "rx_process: device input must be 16-byte aligned");
+    } else {
+        return fail(SDRHIP_EINVAL, "mem must be SDRHIP_MEM_HOST or SDRHIP_MEM_DEVICE");
+    }
+
+    // ---- work area: slot 0 = the frame being filled, grows to done + 1 slots
+    const size_t need = done + 1;
+    if (need > rx->cap_frames) {
+        DevBuf nw;
+        const size_t ncap = need + need / 2;
+        if ((rc = nw.reserve((size_t)S * ncap * frame_bytes))) return rc;
+        if (rx->cap_frames) // keep the partial frame of every stream
+            HIP_TRY(hipMemcpy2DAsync(nw.p, ncap * frame_bytes, rx->work.p, rx->cap_frames * frame_bytes, frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        rx->work.release();
+        rx->work = nw;
+        rx->cap_frames = ncap;
+    }
+    uint8_t *work = rx->work.as<uint8_t>();
+    const size_t stream_bytes = rx->cap_frames * frame_bytes;
+
+    // ---- decimate straight into the frame layout
+    unsigned ss = rx->cfg.sample_bits;
+    size_t n_out = 0;
+    rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, reinterpret_cast<int16_t *>(work), stream_bytes / 4, &n_out, 1,
+                         FB, rx->pending_samples);
+    if (rc) return rc;
+
+    // ---- meta blocks + headers of the frames started by this call (UDPSinkFEC.cpp:87-132)
+    const int first_new = rx->frame_open ? 1 : 0;
+    const int started = (int)(done + (rest > 0 ? 1 : 0)) - first_new; // frames whose first sample arrived now
+    if (started > 0) {
+        uint8_t m[24];
+        const uint32_t fc = rx->cfg.center_frequency_khz, sr = rx->cfg.sample_rate;
+        memcpy(m + 0, &fc, 4); memcpy(m + 4, &sr, 4);
+        m[8] = (uint8_t)((ss - 1) / 8 + 1); // setSampleBytes((sampleSize - 1) / 8 + 1), sdrdaemonrx.cpp:643
+        m[9] = (uint8_t)ss;                 // setSampleBits(sampleSize), :642
+        m[10] = SDRHIP_NB_ORIGINAL; m[11] = (uint8_t)R;
+        memcpy(m + 12, &tv_sec, 4); memcpy(m + 16, &tv_usec, 4);
+        // boost::crc_32_type over the first 20 bytes (UDPSinkFEC.cpp:106-109)
+        uint32_t crc = 0xFFFFFFFFu;
+        for (int i = 0; i < 20; ++i) {
+            crc ^= m[i];
+            for (int k = 0; k < 8; ++k) crc = (crc & 1) ? 0xEDB88320u ^ (crc >> 1) : crc >> 1;
+        }
+        crc ^= 0xFFFFFFFFu;
+        memcpy(m + 20, &crc, 4);
+        HIP_TRY(hipMemcpyAsync(rx->meta.p, m, 24, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream)); // m is a stack temporary
+        hipError_t e = launch_frame_meta(work, stream_bytes, FB, S, first_new, started, (unsigned)rx->frame_count + first_new,
+                                         rx->meta.as<uint8_t>(), c->stream);
+        if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "frame meta launch: %s", hipGetErrorString(e));
+    }
+
+    // ---- FEC over the completed frames of every stream, recovery blocks land behind block 127
+    if (done && R > 0) {
+        for (int s = 0; s < S; ++s) { // (one launch per stream keeps the frame stride uniform)
+            uint8_t *fs = work + (size_t)s * stream_bytes;
+            if ((rc = fec_encode_device(c, fs, frame_bytes, done, R, fs + (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE, frame_bytes))) return rc;
+        }
+    }
+    if (done) {
+        HIP_TRY(hipMemcpy2DAsync(frames_out, S > 1 ? frame_stride_bytes : done * frame_bytes, work, stream_bytes, done * frame_bytes, S,
+                                 mem == SDRHIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
+        // the frame still being filled moves to slot 0
+        if (rest > 0)
+            HIP_TRY(hipMemcpy2DAsync(work, stream_bytes, work + done * frame_bytes, stream_bytes, frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
+    }
+    rx->pending_samples = rest;
+    rx->frame_open = rest > 0;
+    rx->frame_count = (uint16_t)(rx->frame_count + done);
+    if (n_frames) *n_frames = done;
+    if (mem == SDRHIP_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDRHIP_OK;
+}
+
+// --------------------------------------------------------------------------- fused Tx pipe
+struct sdrhip_tx {
+    sdrhip_ctx *ctx;
+    int nstreams;
+    int log2interp;
+    sdrhip_interpolators *itp;
+    DevBuf rxbuf, payload, outbuf;
+};
+
+extern "C" int sdrhip_tx_create(sdrhip_ctx *ctx, int nstreams, int log2interp, sdrhip_tx **out)
+{
+    if (!ctx || !out || nstreams <= 0) return fail(SDRHIP_EINVAL, "tx_create: bad argument");
+    if (log2interp < 0 || log2interp > 6) return fail(SDRHIP_EINVAL, "Invalid log2 interpolation factor");
+    sdrhip_tx *tx = new (std::nothrow) sdrhip_tx();
+    if (!tx) return fail(SDRHIP_ENOMEM, "out of host memory");
+    tx->ctx = ctx; tx->nstreams = nstreams; tx->log2interp = log2interp; tx->itp = nullptr;
+    int rc = sdrhip_interpolators_create(ctx, nstreams, &tx->itp);
+    if (rc) { delete tx; return rc; }
+    *out = tx;
+    return SDRHIP_OK;
+}
+
+extern "C" void sdrhip_tx_destroy(sdrhip_tx *tx)
+{
+    if (!tx) return;
+    sdrhip_interpolators_destroy(tx->itp);
+    tx->rxbuf.release(); tx->payload.release(); tx->outbuf.release();
+    delete tx;
+}
+
+extern "C" int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t *indices, size_t nframes, size_t rx_stride_bytes,
+                                 int16_t *iq_out, size_t out_stride, size_t *n_out, int mem)
+{
+    if (!tx) return fail(SDRHIP_EINVAL, "tx is NULL");
+    const size_t n_payload = nframes * SDRHIP_SAMPLES_PER_FRAME;
+    const size_t n_res = n_payload << tx->log2interp;
+    if (n_out) *n_out = n_res;
+    if (nframes == 0) return SDRHIP_OK;
+    if (!rx || !iq_out) return fail(SDRHIP_EINVAL, "tx_process: NULL buffer");
+    sdrhip_ctx *c = tx->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int S = tx->nstreams;
+    const size_t fb = (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE;
+    if (S == 1) { rx_stride_bytes = nframes * fb; out_stride = n_res; }
+    if (rx_stride_bytes < nframes * fb || out_stride < n_res) return fail(SDRHIP_EINVAL, "tx_process: stride too small");
+    int rc;
+    const uint8_t *drx = rx;
+    std::vector<uint8_t> idx;
+    if (mem == SDRHIP_MEM_HOST) {
+        if ((rc = tx->rxbuf.reserve((size_t)S * nframes * fb))) return rc;
+        HIP_TRY(hipMemcpy2DAsync(tx->rxbuf.p, nframes * fb, rx, rx_stride_bytes, nframes * fb, S, hipMemcpyHostToDevice, c->stream));
+        drx = tx->rxbuf.as<uint8_t>();
+        if (!indices) {
+            idx.resize((size_t)S * nframes * SDRHIP_NB_ORIGINAL);
+            for (int s = 0; s < S; ++s)
+                for (size_t i = 0; i < nframes * SDRHIP_NB_ORIGINAL; ++i)
+                    idx[(size_t)s * nframes * SDRHIP_NB_ORIGINAL + i] = rx[(size_t)s * rx_stride_bytes + i * SDRHIP_UDPSIZE + 2];
+            indices = idx.data();
+        }
+    } else if (mem == SDRHIP_MEM_DEVICE) {
+        if (!indices) return fail(SDRHIP_EINVAL, "tx_process: device mode needs the host `indices` array");
+        if (!aligned16(iq_out) || (S > 1 && (out_stride & 3))) return fail(SDRHIP_EALIGN, "tx_process: device output must be 16-byte aligned");
+        if (S > 1 && rx_stride_bytes != nframes * fb) return fail(SDRHIP_EINVAL, "tx_process: device rx must be contiguous per stream");
+    } else {
+        return fail(SDRHIP_EINVAL, "mem must be SDRHIP_MEM_HOST or SDRHIP_MEM_DEVICE");
+    }
+    // decode all S * nframes frames in one batch: payload [S][nframes][127 * 508] = [S][n_payload] samples
+    const size_t pstride = (n_payload + 3) & ~(size_t)3; // samples
+    if ((rc = tx->payload.reserve((size_t)S * pstride * 4 + 16))) return rc;
+    if (pstride == n_payload) {
+        if ((rc = fec_decode_device(c, drx, fb, indices, (size_t)S * nframes, tx->payload.as<uint8_t>(), (size_t)127 * SDRHIP_BLOCK_BYTES, nullptr))) return rc;
+    } else {
+        for (int s = 0; s < S; ++s)
+            if ((rc = fec_decode_device(c, drx + (size_t)s * nframes * fb, fb, indices + (size_t)s * nframes * SDRHIP_NB_ORIGINAL, nframes,
+                                        tx->payload.as<uint8_t>() + (size_t)s * pstride * 4, (size_t)127 * SDRHIP_BLOCK_BYTES, nullptr)))
+                return rc;
+    }
+    int16_t *dout = iq_out;
+    size_t dos = out_stride;
+    if (mem == SDRHIP_MEM_HOST) {
+        dos = (n_res + 3) & ~(size_t)3;
+        if ((rc = tx->outbuf.reserve((size_t)S * dos * 4 + 16))) return rc;
+        dout = tx->outbuf.as<int16_t>();
+    }
+    if ((rc = interpolate_device(tx->itp, tx->log2interp, tx->payload.as<int16_t>(), n_payload, pstride, dout, dos, nullptr))) return rc;
+    if (mem == SDRHIP_MEM_HOST) {
+        HIP_TRY(hipMemcpy2DAsync(iq_out, out_stride * 4, dout, dos * 4, n_res * 4, S, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SDRHIP_OK;
+}

@@ -1,0 +1,417 @@
+"""Host-side mirror of the reference's interface for the hot path, on top of libsdrhip.so.
+
+Class and method names follow the reference (Decimators.h:32-71, Interpolators.h:35-61,
+Downsampler.h:26-83, Upsampler.h:27-70, the CM256 call sites UDPSinkFEC.cpp:195-246 /
+SDRdaemonFECBuffer.cpp:148-213) so that the parity tests read like code written against the
+reference.  Every method accepts
+
+  * numpy int16 arrays  -> SDRHIP_MEM_HOST (staged through the GPU, synchronous), or
+  * torch int16 CUDA tensors -> SDRHIP_MEM_DEVICE (zero-copy, enqueued on the context stream).
+
+Shapes: one stream (n, 2); a bank of S streams (S, n, 2).  There is no CPU implementation
+behind these classes: without libsdrhip.so or without a GPU they raise.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (BLOCK_BYTES, FC_CEN, FC_INF, FC_SUP, HB_DB, HB_EO1, MEM_DEVICE, MEM_HOST, NB_ORIGINAL,  # noqa: F401
+                   SAMPLES_PER_FRAME, UDPSIZE, CM256Block, CM256Params, RxConfig, SdrHipError, check)
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def device_count():
+    return _lib.lib().sdrhip_device_count()
+
+
+class Context:
+    """One per GPU (sdrhip_ctx).  stream: a torch.cuda.Stream, a raw hipStream_t int, or None
+    (torch's current stream when torch sees the device, else the null stream)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = _lib.lib()
+        self.device = device
+        if stream is None and torch is not None and torch.cuda.is_available():
+            with torch.cuda.device(device):
+                stream = torch.cuda.current_stream().cuda_stream
+        elif stream is not None and hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        self.h = C.c_void_p()
+        check(self.lib.sdrhip_ctx_create(device, C.c_void_p(stream or 0), C.byref(self.h)))
+
+    def synchronize(self):
+        check(self.lib.sdrhip_ctx_synchronize(self.h))
+
+    def timing_begin(self):
+        check(self.lib.sdrhip_ctx_timing_begin(self.h))
+
+    def timing_end(self):
+        ms = C.c_float(0)
+        check(self.lib.sdrhip_ctx_timing_end(self.h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.lib.sdrhip_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _bank_view(iq, nstreams):
+    """-> (array (S, n, 2) contiguous-per-stream, is_torch, squeeze)"""
+    squeeze = False
+    if _is_torch(iq):
+        if iq.dtype != torch.int16 or not iq.is_cuda:
+            raise TypeError("torch input must be an int16 CUDA tensor")
+        if iq.dim() == 2:
+            iq, squeeze = iq.unsqueeze(0), True
+        if iq.dim() != 3 or iq.shape[2] != 2 or iq.shape[0] != nstreams:
+            raise ValueError("expected shape (%d, n, 2)" % nstreams)
+        if iq.stride(2) != 1 or iq.stride(1) != 2:
+            iq = iq.contiguous()
+        return iq, True, squeeze
+    a = np.asarray(iq)
+    if a.dtype != np.int16:
+        raise TypeError("numpy input must be int16")
+    if a.ndim == 2:
+        a, squeeze = a[None], True
+    if a.ndim != 3 or a.shape[2] != 2 or a.shape[0] != nstreams:
+        raise ValueError("expected shape (%d, n, 2)" % nstreams)
+    return np.ascontiguousarray(a), False, squeeze
+
+
+def _ptr(x):
+    return C.c_void_p(x.data_ptr()) if _is_torch(x) else C.c_void_p(x.ctypes.data)
+
+
+def _stride_samples(x):
+    return (x.stride(0) // 2) if _is_torch(x) else (x.strides[0] // 4)
+
+
+def _alloc_like(x, shape, dtype_np=np.int16):
+    if _is_torch(x):
+        tdt = {np.int16: torch.int16, np.uint8: torch.uint8}[dtype_np]
+        # rows padded to 16 bytes so that every stream starts aligned
+        return torch.empty(shape, dtype=tdt, device=x.device)
+    return np.empty(shape, dtype=dtype_np)
+
+
+class Decimators:
+    """Bank of reference `Decimators` objects (Decimators.h:32-71)."""
+
+    def __init__(self, ctx, nstreams=1, hb_variant=HB_EO1):
+        self.ctx, self.nstreams = ctx, nstreams
+        self.h = C.c_void_p()
+        check(ctx.lib.sdrhip_decimators_create(ctx.h, nstreams, hb_variant, C.byref(self.h)))
+
+    def reset(self):
+        check(self.ctx.lib.sdrhip_decimators_reset(self.h))
+
+    def decimate(self, log2decim, fcpos, sample_size, iq, out=None):
+        """Decimators::decimate<2^log2decim>_{inf,sup,cen}(sampleSize, in, out).
+        Returns (out, new_sample_size)."""
+        x, is_t, squeeze = _bank_view(iq, self.nstreams)
+        S, n = x.shape[0], x.shape[1]
+        n_res = n >> log2decim
+        if out is None:
+            if is_t:  # per-stream rows padded to a multiple of 4 samples (16-byte aligned rows)
+                pad = (n_res + 3) & ~3
+                buf = torch.empty((S, max(pad, 4), 2), dtype=torch.int16, device=x.device)
+                out = buf[:, :n_res]
+            else:
+                out = np.empty((S, n_res, 2), dtype=np.int16)
+        if is_t and S > 1 and (x.stride(0) // 2) % 4:
+            raise ValueError("device bank input: per-stream stride must be a multiple of 4 samples")
+        ss = C.c_uint(sample_size)
+        n_out = C.c_size_t(0)
+        check(self.ctx.lib.sdrhip_decimate(self.h, log2decim, fcpos, C.byref(ss), _ptr(x), n, _stride_samples(x), _ptr(out),
+                                           _stride_samples(out) if S > 1 else n_res, C.byref(n_out),
+                                           MEM_DEVICE if is_t else MEM_HOST))
+        assert n_out.value == n_res
+        return (out[0] if squeeze else out), ss.value
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.sdrhip_decimators_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Downsampler:
+    """Reference `Downsampler` (Downsampler.h:26-83): configuration + dispatch."""
+
+    def __init__(self, ctx, decim=0, fcpos=FC_CEN, nstreams=1, hb_variant=HB_EO1):
+        self.m_decim, self.m_fcPos = decim, fcpos
+        self.m_error = ""
+        self.m_decimators = Decimators(ctx, nstreams, hb_variant)
+
+    def configure(self, m):
+        """m: dict of the parsekv pairs (Downsampler.cpp:32-67).  Returns False and sets error()
+        on an invalid value, like the reference."""
+        if "decim" in m:
+            v = int(m["decim"])
+            if v < 0 or v > 6:
+                self.m_error = "Invalid log2 decimation factor"
+                return False
+            self.m_decim = v
+        if "fcpos" in m:
+            v = int(m["fcpos"])
+            if v < FC_INF or v > FC_CEN:
+                self.m_error = "Invalid Fc position index"
+                return False
+            self.m_fcPos = v
+        return True
+
+    def getLog2Decimation(self):
+        return self.m_decim
+
+    def error(self):
+        e, self.m_error = self.m_error, ""
+        return e
+
+    def __bool__(self):
+        return not self.m_error
+
+    def process(self, sample_size, samples_in):
+        """Downsampler::process (Downsampler.cpp:74-162) -> (samples_out, sampleSize)."""
+        return self.m_decimators.decimate(self.m_decim, self.m_fcPos, sample_size, samples_in)
+
+    def rescale(self, sample_size, samples_inout):
+        """Downsampler::rescale = Decimators::decimate1 (Downsampler.cpp:69-72)."""
+        return self.m_decimators.decimate(0, self.m_fcPos, sample_size, samples_inout)
+
+
+class Interpolators:
+    """Bank of reference `Interpolators` objects (Interpolators.h:35-61)."""
+
+    def __init__(self, ctx, nstreams=1):
+        self.ctx, self.nstreams = ctx, nstreams
+        self.h = C.c_void_p()
+        check(ctx.lib.sdrhip_interpolators_create(ctx.h, nstreams, C.byref(self.h)))
+
+    def reset(self):
+        check(self.ctx.lib.sdrhip_interpolators_reset(self.h))
+
+    def interpolate(self, log2interp, iq, out=None):
+        """Interpolators::interpolate<2^log2interp>_cen(in, out)."""
+        x, is_t, squeeze = _bank_view(iq, self.nstreams)
+        S, n = x.shape[0], x.shape[1]
+        n_res = n << log2interp
+        if out is None:
+            if is_t:
+                pad = (n_res + 3) & ~3
+                out = torch.empty((S, max(pad, 4), 2), dtype=torch.int16, device=x.device)[:, :n_res]
+            else:
+                out = np.empty((S, n_res, 2), dtype=np.int16)
+        n_out = C.c_size_t(0)
+        check(self.ctx.lib.sdrhip_interpolate(self.h, log2interp, _ptr(x), n, _stride_samples(x), _ptr(out),
+                                              _stride_samples(out) if S > 1 else n_res, C.byref(n_out),
+                                              MEM_DEVICE if is_t else MEM_HOST))
+        return out[0] if squeeze else out
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.sdrhip_interpolators_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Upsampler:
+    """Reference `Upsampler` (Upsampler.h:27-70)."""
+
+    def __init__(self, ctx, interp=0, nstreams=1):
+        self.m_interp = interp
+        self.m_error = ""
+        self.m_interpolators = Interpolators(ctx, nstreams)
+
+    def configure(self, m):
+        if "interp" in m:
+            v = int(m["interp"])
+            if v < 0 or v > 6:
+                self.m_error = "Invalid log2 interpolation factor"
+                return False
+            self.m_interp = v
+        return True
+
+    def getLog2Interpolation(self):
+        return self.m_interp
+
+    def error(self):
+        e, self.m_error = self.m_error, ""
+        return e
+
+    def process(self, samples_in):
+        return self.m_interpolators.interpolate(self.m_interp, samples_in)
+
+
+class CM256:
+    """The `CM256` object of the reference's call sites (UDPSinkFEC.h:123, SDRdaemonFECBuffer.h:173)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def isInitialized(self):
+        return True
+
+    def cm256_encode(self, params, originals, recovery_out=None):
+        """originals: (k, BlockBytes) uint8 numpy (taken positionally).  Returns (rc, recovery)."""
+        k, m, bb = params
+        originals = np.ascontiguousarray(originals, dtype=np.uint8)
+        blocks = (CM256Block * k)()
+        for i in range(k):
+            blocks[i].Block = originals[i].ctypes.data
+            blocks[i].Index = i
+        rec = np.zeros((m, bb), dtype=np.uint8) if recovery_out is None else recovery_out
+        rc = self.ctx.lib.sdrhip_cm256_encode(self.ctx.h, CM256Params(k, m, bb), blocks, C.c_void_p(rec.ctypes.data))
+        return rc, rec
+
+    def cm256_decode(self, params, data, indices):
+        """data: (k, BlockBytes) uint8 received blocks, modified in place; indices: their Index
+        fields.  Returns (rc, indices_after) -- the library's in-place contract."""
+        k, m, bb = params
+        assert data.dtype == np.uint8 and data.flags.c_contiguous and data.shape == (k, bb)
+        blocks = (CM256Block * k)()
+        for i in range(k):
+            blocks[i].Block = data[i].ctypes.data
+            blocks[i].Index = int(indices[i])
+        rc = self.ctx.lib.sdrhip_cm256_decode(self.ctx.h, CM256Params(k, m, bb), blocks)
+        return rc, np.array([blocks[i].Index for i in range(k)], dtype=np.uint8)
+
+
+def fec_encode_frames(ctx, frames, nb_fec):
+    """frames (F, 128, 512) uint8 (numpy or CUDA tensor) -> recovery super blocks (F, nb_fec, 512)."""
+    is_t = _is_torch(frames)
+    F = frames.shape[0]
+    if not is_t:
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    out = torch.zeros((F, nb_fec, 512), dtype=torch.uint8, device=frames.device) if is_t else np.zeros((F, nb_fec, 512), np.uint8)
+    check(ctx.lib.sdrhip_fec_encode_frames(ctx.h, _ptr(frames), F, nb_fec, _ptr(out), MEM_DEVICE if is_t else MEM_HOST))
+    return out
+
+
+def fec_decode_frames(ctx, rx, indices=None, want_block0=False):
+    """rx (F, 128, 512) uint8: first 128 received super blocks per frame, arrival order.
+    -> payload (F, 127*508) uint8 [, block0 (F, 508)]"""
+    is_t = _is_torch(rx)
+    F = rx.shape[0]
+    if not is_t:
+        rx = np.ascontiguousarray(rx, dtype=np.uint8)
+    if indices is None:
+        indices = (rx[:, :, 2].cpu().numpy() if is_t else rx[:, :, 2])
+    indices = np.ascontiguousarray(indices, dtype=np.uint8)
+    if is_t:
+        payload = torch.empty((F, 127 * 508), dtype=torch.uint8, device=rx.device)
+        b0 = torch.empty((F, 508), dtype=torch.uint8, device=rx.device) if want_block0 else None
+    else:
+        payload = np.empty((F, 127 * 508), np.uint8)
+        b0 = np.empty((F, 508), np.uint8) if want_block0 else None
+    check(ctx.lib.sdrhip_fec_decode_frames(ctx.h, _ptr(rx), C.c_void_p(indices.ctypes.data), F, _ptr(payload),
+                                           _ptr(b0) if want_block0 else C.c_void_p(0), MEM_DEVICE if is_t else MEM_HOST))
+    return (payload, b0) if want_block0 else payload
+
+
+class RxPipe:
+    """Downsampler -> UDPSinkFEC framing -> CM256 encode for a bank of streams (sdrhip_rx)."""
+
+    def __init__(self, ctx, nstreams=1, log2decim=4, fcpos=FC_CEN, hb_variant=HB_EO1, sample_bits=16, nb_fec=32,
+                 center_frequency_khz=435000, sample_rate=625000):
+        self.ctx, self.nstreams, self.nb_fec = ctx, nstreams, nb_fec
+        self.cfg = RxConfig(log2decim, fcpos, hb_variant, sample_bits, nb_fec, center_frequency_khz, sample_rate)
+        self.h = C.c_void_p()
+        check(ctx.lib.sdrhip_rx_create(ctx.h, nstreams, C.byref(self.cfg), C.byref(self.h)))
+
+    def max_frames(self, n_in):
+        return self.ctx.lib.sdrhip_rx_max_frames(self.h, n_in)
+
+    def process(self, iq, tv_sec=0, tv_usec=0, out=None):
+        """-> frames (S, n_frames, 128 + nb_fec, 512) uint8 (squeezed for one stream)"""
+        x, is_t, squeeze = _bank_view(iq, self.nstreams)
+        S, n = x.shape[0], x.shape[1]
+        cap = max(self.max_frames(n), 1)
+        fb = (NB_ORIGINAL + self.nb_fec) * UDPSIZE
+        if out is None:
+            out = (torch.empty((S, cap, NB_ORIGINAL + self.nb_fec, UDPSIZE), dtype=torch.uint8, device=x.device) if is_t
+                   else np.empty((S, cap, NB_ORIGINAL + self.nb_fec, UDPSIZE), np.uint8))
+        nf = C.c_size_t(0)
+        check(self.ctx.lib.sdrhip_rx_process(self.h, _ptr(x), n, _stride_samples(x), tv_sec, tv_usec, _ptr(out), cap * fb,
+                                             C.byref(nf), MEM_DEVICE if is_t else MEM_HOST))
+        out = out[:, :nf.value]
+        return out[0] if squeeze else out
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.sdrhip_rx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TxPipe:
+    """SDRdaemonFECBuffer decode -> Upsampler for a bank of streams (sdrhip_tx)."""
+
+    def __init__(self, ctx, nstreams=1, log2interp=4):
+        self.ctx, self.nstreams, self.log2interp = ctx, nstreams, log2interp
+        self.h = C.c_void_p()
+        check(ctx.lib.sdrhip_tx_create(ctx.h, nstreams, log2interp, C.byref(self.h)))
+
+    def process(self, rx, indices=None):
+        """rx (S, F, 128, 512) uint8 (or (F, 128, 512)) -> iq (S, F*16129 << log2interp, 2) int16"""
+        is_t = _is_torch(rx)
+        squeeze = rx.ndim == 3
+        if squeeze:
+            rx = rx[None]
+        S, F = rx.shape[0], rx.shape[1]
+        if not is_t:
+            rx = np.ascontiguousarray(rx, dtype=np.uint8)
+        else:
+            rx = rx.contiguous()
+        if indices is None:
+            indices = (rx[:, :, :, 2].cpu().numpy() if is_t else rx[:, :, :, 2])
+        indices = np.ascontiguousarray(indices, dtype=np.uint8)
+        n_res = (F * SAMPLES_PER_FRAME) << self.log2interp
+        pad = (n_res + 3) & ~3
+        out = (torch.empty((S, pad, 2), dtype=torch.int16, device=rx.device) if is_t else np.empty((S, pad, 2), np.int16))
+        n_out = C.c_size_t(0)
+        check(self.ctx.lib.sdrhip_tx_process(self.h, _ptr(rx), C.c_void_p(indices.ctypes.data), F, F * NB_ORIGINAL * UDPSIZE,
+                                             _ptr(out), pad, C.byref(n_out), MEM_DEVICE if is_t else MEM_HOST))
+        out = out[:, :n_res]
+        return out[0] if squeeze else out
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.sdrhip_tx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,146 @@
+"""GPU parity of the decimators: HIP path (through the C ABI) vs the oracle and vs the committed
+golden vectors of the real reference.  Bit-exact (integer work)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import signals
+from golden_util import Golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import sdrdaemon_amd as sd
+
+    assert sd.device_count() > 0, "GPU tests need a GPU and libsdrhip.so"
+    return sd.Context(0)
+
+
+def test_golden_vectors_all_decimator_entry_points(ctx):
+    """Every Decimators entry point x sampleSize 8/12/16 x EO1/DB x ragged chunked calls, expected
+    outputs produced by the compiled reference (tests/golden/make_golden.py)."""
+    import sdrdaemon_amd as sd
+
+    G = Golden()
+    n = 0
+    for case in G.cases:
+        if case["kind"] != "decimate":
+            continue
+        x = G.input(case)
+        d = sd.Decimators(ctx, 1, case["bias"])
+        pos, outs, ss_out = 0, [], None
+        for c in case["chunks"]:
+            o, ss_out = d.decimate(case["log2"], case["fcpos"], case["sample_size"], x[pos:pos + c])
+            outs.append(o)
+            pos += c
+        assert ss_out == case["sample_size_out"], case["key"]
+        assert np.array_equal(np.concatenate(outs), G.expected(case)), case["key"]
+        n += 1
+    assert n == 2 * (3 * 7 * 4 + 3 * 3 * 7)
+
+
+@pytest.mark.parametrize("signal", sorted(signals.ALL))
+def test_vs_oracle_multi_segment(ctx, oracle, signal):
+    """Long enough for several segments (warm-up path) and a ragged tail; both rounding modes."""
+    import sdrdaemon_amd as sd
+
+    x = signals.ALL[signal](300000 + 77)
+    for bias in (0, 1):
+        for log2, fcpos in ((4, 2), (4, 0), (3, 1), (6, 2), (1, 2), (5, 0), (2, 2), (6, 1)):
+            d, od = sd.Decimators(ctx, 1, bias), oracle.decimators(bias)
+            for seg in (x[:200001], x[200001:]):
+                a, sa = d.decimate(log2, fcpos, 16, seg)
+                b, sb = od.decimate(log2, fcpos, 16, seg)
+                assert sa == sb
+                assert np.array_equal(a, b), (signal, bias, log2, fcpos, np.argwhere(a != b)[:4])
+
+
+def test_mode_switch_keeps_filter_state(ctx, oracle):
+    """m_decimator2..64 are shared by all modes (Decimators.h:56-70); includes the cen-after-inf
+    case where the first filter's history no longer fits int16."""
+    import sdrdaemon_amd as sd
+
+    x = signals.noise(8 * 8192, 99)
+    for bias in (0, 1):
+        d, od = sd.Decimators(ctx, 1, bias), oracle.decimators(bias)
+        plan = [(4, 2), (4, 0), (4, 2), (3, 1), (6, 2), (2, 2), (5, 0), (1, 2)]
+        for i, (log2, fcpos) in enumerate(plan):
+            seg = x[i * 8192:(i + 1) * 8192]
+            a, _ = d.decimate(log2, fcpos, 16, seg)
+            b, _ = od.decimate(log2, fcpos, 16, seg)
+            assert np.array_equal(a, b), (bias, i, log2, fcpos)
+
+
+def test_tiny_and_empty_calls(ctx, oracle):
+    import sdrdaemon_amd as sd
+
+    x = signals.noise(5000, 3)
+    d, od = sd.Decimators(ctx, 1, 0), oracle.decimators(0)
+    pos = 0
+    for n in (16, 0, 17, 31, 32, 1, 15, 160, 4096, 3):
+        seg = x[pos:pos + n]
+        pos += n
+        a, _ = d.decimate(4, 2, 16, seg)
+        b, _ = od.decimate(4, 2, 16, seg)
+        assert a.shape == b.shape and np.array_equal(a, b), n
+
+
+def test_bank_of_streams_device_memory(ctx, oracle):
+    """64 independent streams in one launch, device-resident tensors (the bench layout)."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    S, n = 64, 65536
+    x = np.stack([signals.noise(n, 1000 + s) for s in range(S)])
+    xd = torch.from_numpy(x).cuda()
+    d = sd.Decimators(ctx, S, 0)
+    ods = [oracle.decimators(0) for _ in range(S)]
+    for rep in range(2):
+        y, ss = d.decimate(4, 2, 16, xd)
+        ctx.synchronize()
+        y = y.cpu().numpy()
+        for s in range(S):
+            e, _ = ods[s].decimate(4, 2, 16, x[s])
+            assert np.array_equal(y[s], e), (rep, s)
+
+
+def test_testsource_blocks_digest(ctx):
+    """16 TestSource-sized blocks (65536, TestSource.h:33) through decimate16_cen: SHA-256 of the
+    real reference's output."""
+    import sdrdaemon_amd as sd
+
+    G = Golden()
+    for b in G.big:
+        if b["kind"] != "decimate16_cen_blocks":
+            continue
+        x = signals.noise(1 << 20, b["seed"])
+        d = sd.Decimators(ctx, 1, b["bias"])
+        h = hashlib.sha256()
+        for i in range(16):
+            o, _ = d.decimate(4, 2, 16, x[i * 65536:(i + 1) * 65536])
+            h.update(o.tobytes())
+        assert h.hexdigest() == b["sha256"]
+
+
+def test_full_size_linearity_property(ctx):
+    """BASELINE config-2 size (2^24 samples per call here): the EO1 cascade is exactly linear for
+    inputs small enough not to truncate differently... instead use the exact property
+    decimate(x) with zero history == decimate computed in two halves (state carry)."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    n = 1 << 22
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randint(-32768, 32768, (n, 2), generator=g, device="cuda", dtype=torch.int16)
+    d1, d2 = sd.Decimators(ctx, 1, 0), sd.Decimators(ctx, 1, 0)
+    whole, _ = d1.decimate(4, 2, 16, x)
+    cut = 1234 * 16
+    a, _ = d2.decimate(4, 2, 16, x[:cut])
+    b, _ = d2.decimate(4, 2, 16, x[cut:].contiguous())
+    ctx.synchronize()
+    assert torch.equal(whole, torch.cat([a, b]))

@@ -1,0 +1,135 @@
+"""GPU parity of the CM256 path (through the C ABI) vs the oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+import signals
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import sdrdaemon_amd as sd
+
+    assert sd.device_count() > 0
+    return sd.Context(0)
+
+
+def test_cm256_encode_matches_oracle(ctx, oracle):
+    import sdrdaemon_amd as sd
+
+    cm = sd.CM256(ctx)
+    rs = np.random.RandomState(4)
+    for k, m, bb in ((128, 32, 508), (128, 1, 508), (128, 128, 508), (5, 3, 33), (16, 16, 64), (2, 2, 1400), (100, 20, 1021)):
+        x = rs.randint(0, 256, size=(k, bb)).astype(np.uint8)
+        rc, rec = cm.cm256_encode((k, m, bb), x)
+        assert rc == 0
+        assert np.array_equal(rec, oracle.cm256_encode(x, m)), (k, m, bb)
+
+
+def _deliver(x, rec, erased, rows):
+    k = x.shape[0]
+    keep = [i for i in range(k) if i not in set(erased)]
+    data = np.concatenate([x[keep], rec[rows]]).copy()
+    idx = np.array(keep + [k + r for r in rows])
+    return data, idx
+
+
+@pytest.mark.parametrize("case", ["stride5_24", "first32", "last32", "random24", "one_row0", "m1_quirk", "none"])
+def test_cm256_decode_matches_oracle(ctx, oracle, case):
+    import sdrdaemon_amd as sd
+
+    cm = sd.CM256(ctx)
+    rs = np.random.RandomState(11)
+    x = rs.randint(0, 256, size=(128, 508)).astype(np.uint8)
+    rec = oracle.cm256_encode(x, 32)
+    if case == "stride5_24":
+        erased, rows = list(range(1, 121, 5)), list(range(24))
+    elif case == "first32":
+        erased, rows = list(range(32)), list(range(32))
+    elif case == "last32":
+        erased, rows = list(range(96, 128)), list(range(31, -1, -1))
+    elif case == "random24":
+        erased = sorted(rs.choice(128, 24, replace=False).tolist())
+        rows = sorted(rs.choice(32, 24, replace=False).tolist())
+    elif case == "one_row0":
+        erased, rows = [77], [0]
+    elif case == "m1_quirk":
+        erased, rows = [9], [2]
+    else:
+        erased, rows = [], []
+    d1, i1 = _deliver(x, rec, erased, rows)
+    d2 = d1.copy()
+    nrec = max(len(rows), 1)
+    rc1, j1 = cm.cm256_decode((128, nrec, 508), d1, i1)
+    rc2, j2 = oracle.cm256_decode(d2, i1, 128, nrec)
+    assert rc1 == rc2 == 0
+    assert np.array_equal(j1, j2)
+    assert np.array_equal(d1, d2)
+    if case not in ("m1_quirk",):
+        out = np.zeros_like(x)
+        out[j1] = d1
+        assert np.array_equal(out, x)
+
+
+def test_decode_duplicate_index_is_an_error(ctx):
+    import sdrdaemon_amd as sd
+
+    cm = sd.CM256(ctx)
+    data = np.zeros((128, 508), np.uint8)
+    idx = np.arange(128)
+    idx[5] = 4
+    idx[127] = 130
+    rc, _ = cm.cm256_decode((128, 2, 508), data, idx)
+    assert rc == -5
+
+
+def test_frames_batch_encode_decode(ctx, oracle):
+    """Batched frame API (the Rx encode / Tx decode call sites), host and device memory, several
+    erasure patterns in one batch including block 0 and lost recovery blocks."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    F, R = 11, 32
+    x = signals.noise(F * 16129, 77)
+    fr = oracle.framer(nb_fec_blocks=R, tv_sec=5, tv_usec=6)
+    frames = fr.write(x)
+    assert frames.shape[0] == F
+    exp_rec = np.stack([oracle.frame_encode(frames[f], R) for f in range(F)])
+    rec_h = sd.fec_encode_frames(ctx, frames, R)
+    assert np.array_equal(rec_h, exp_rec)
+    rec_d = sd.fec_encode_frames(ctx, torch.from_numpy(frames).cuda(), R)
+    ctx.synchronize()
+    assert np.array_equal(rec_d.cpu().numpy(), exp_rec)
+
+    rs = np.random.RandomState(8)
+    rx = np.zeros((F, 128, 512), np.uint8)
+    for f in range(F):
+        allb = np.concatenate([frames[f], exp_rec[f]])
+        if f % 3 == 0:
+            lost = set(range(1, 121, 5))  # pattern A: 24 originals at stride 5
+        elif f % 3 == 1:
+            lost = set(rs.choice(160, 24, replace=False).tolist()) | {0}  # pattern B incl. block 0
+        else:
+            lost = set()
+        keep = [i for i in range(160) if i not in lost][:128]
+        rx[f] = allb[keep]
+    payload, b0 = sd.fec_decode_frames(ctx, rx, want_block0=True)
+    for f in range(F):
+        assert np.array_equal(payload[f].view(np.int16).reshape(-1, 2), x[f * 16129:(f + 1) * 16129]), f
+        assert np.array_equal(b0[f], frames[f, 0, 4:]), f
+    pd = sd.fec_decode_frames(ctx, torch.from_numpy(rx).cuda())
+    ctx.synchronize()
+    assert np.array_equal(pd.cpu().numpy(), payload)
+
+
+def test_incomplete_frame_keeps_zeros(ctx, oracle):
+    """< 128 blocks cannot happen in the batched API (it takes the first 128), but a frame whose
+    128 received blocks contain no recovery block is passed through untouched."""
+    import sdrdaemon_amd as sd
+
+    x = signals.noise(16129, 5)
+    frames = oracle.framer(nb_fec_blocks=0).write(x)
+    payload = sd.fec_decode_frames(ctx, frames)
+    assert np.array_equal(payload[0].view(np.int16).reshape(-1, 2), x)

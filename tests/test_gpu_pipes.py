@@ -1,0 +1,174 @@
+"""GPU parity of the interpolators and of the fused Rx / Tx pipes vs oracle + golden vectors."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import signals
+from golden_util import Golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import sdrdaemon_amd as sd
+
+    assert sd.device_count() > 0
+    return sd.Context(0)
+
+
+def test_golden_vectors_all_interpolator_entry_points(ctx):
+    import sdrdaemon_amd as sd
+
+    G = Golden()
+    n = 0
+    for case in G.cases:
+        if case["kind"] != "interpolate":
+            continue
+        x = G.input(case)
+        u = sd.Interpolators(ctx, 1)
+        pos, outs = 0, []
+        for c in case["chunks"]:
+            outs.append(u.interpolate(case["log2"], x[pos:pos + c]))
+            pos += c
+        assert np.array_equal(np.concatenate(outs), G.expected(case)), case["key"]
+        n += 1
+    assert n == 2 * 3 * 7
+
+
+@pytest.mark.parametrize("signal", ["noise", "alternating", "mixed", "cw_full", "zeros"])
+def test_interpolators_vs_oracle_multi_segment(ctx, oracle, signal):
+    import sdrdaemon_amd as sd
+
+    x = signals.ALL[signal](70000 + 13)
+    for log2 in range(0, 7):
+        u, ou = sd.Interpolators(ctx, 1), oracle.interpolators()
+        for seg in (x[:40001], x[40001:40002], x[40002:]):
+            a = u.interpolate(log2, seg)
+            b = ou.interpolate(log2, seg)
+            assert np.array_equal(a, b), (signal, log2, np.argwhere(a != b)[:4])
+
+
+def test_interpolate16_frames_digest(ctx):
+    import sdrdaemon_amd as sd
+
+    G = Golden()
+    for b in G.big:
+        if b["kind"] != "interpolate16_cen" or b["flavour"] != "eo1":
+            continue
+        x = signals.noise(1 << 20, b["seed"])[:b["n"]]
+        y = sd.Interpolators(ctx, 1).interpolate(4, x)
+        assert hashlib.sha256(y.tobytes()).hexdigest() == b["sha256"]
+
+
+def test_interpolator_bank_device_memory(ctx, oracle):
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    S, n = 16, 16129
+    x = np.stack([signals.noise(n + 3, 50 + s) for s in range(S)])[:, :n + 3]
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    u = sd.Interpolators(ctx, S)
+    y = u.interpolate(4, xd[:, :n + 3])
+    ctx.synchronize()
+    y = y.cpu().numpy()
+    for s in range(S):
+        assert np.array_equal(y[s], oracle.interpolators().interpolate(4, x[s])), s
+
+
+@pytest.mark.parametrize("cfg", [(4, 2, 0, 16, 32), (4, 0, 1, 16, 8), (3, 2, 0, 12, 0), (6, 2, 0, 8, 128), (1, 2, 1, 16, 1)])
+def test_rx_pipe_matches_reference_chain(ctx, oracle, cfg):
+    """decimate -> UDPSinkFEC::write framing -> cm256_encode, ragged calls, frames straddling
+    calls, meta stamped per call; expected = oracle decimator + framer + frame_encode."""
+    import sdrdaemon_amd as sd
+
+    log2, fcpos, bias, bits, R = cfg
+    nsamp = (3 * 16129 + 5000) << log2
+    x = signals.noise(nsamp, 31, bits)
+    rx = sd.RxPipe(ctx, 1, log2decim=log2, fcpos=fcpos, hb_variant=bias, sample_bits=bits, nb_fec=R,
+                   center_frequency_khz=435000, sample_rate=625000)
+    od = oracle.decimators(bias)
+    fr = None
+    cuts = [0, nsamp // 3 + 5, nsamp // 3 + 5 + (1 << log2) * 1000, nsamp]
+    got, exp = [], []
+    for i in range(3):
+        seg = x[cuts[i]:cuts[i + 1]]
+        g = rx.process(seg, tv_sec=100 + i, tv_usec=7 * i)
+        y, ss = od.decimate(log2, fcpos, bits, seg)
+        if fr is None:
+            fr = oracle.framer(nb_fec_blocks=R, sample_bytes=(ss - 1) // 8 + 1, sample_bits=ss)
+        fr.s.tv_sec, fr.s.tv_usec = 100 + i, 7 * i
+        e = fr.write(y)
+        got.append(g)
+        exp.append(e)
+    got, exp = np.concatenate(got), np.concatenate(exp)
+    assert got.shape[0] == exp.shape[0] == 3
+    for f in range(3):
+        assert np.array_equal(got[f, :128], exp[f]), (cfg, f)
+        if R:
+            assert np.array_equal(got[f, 128:], oracle.frame_encode(exp[f], R)), (cfg, f)
+
+
+def test_rx_bank_device(ctx, oracle):
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    S, n = 8, 4 * 65536 + 64
+    x = np.stack([signals.cw(n, 3276.8 * (1 + s), 100e3, 10e6, start=17 * s) for s in range(S)])
+    rx = sd.RxPipe(ctx, S, log2decim=4, nb_fec=32)
+    g = rx.process(torch.from_numpy(x).cuda(), 9, 9)
+    ctx.synchronize()
+    g = g.cpu().numpy()
+    assert g.shape[:2] == (S, 1)
+    for s in range(S):
+        y, _ = oracle.decimators(0).decimate(4, 2, 16, x[s])
+        e = oracle.framer(nb_fec_blocks=32, tv_sec=9, tv_usec=9).write(y)
+        assert np.array_equal(g[s, 0, :128], e[0]), s
+        assert np.array_equal(g[s, 0, 128:], oracle.frame_encode(e[0], 32)), s
+
+
+def test_tx_pipe_matches_reference_chain(ctx, oracle):
+    """config 4: 24 erased blocks per frame (pattern A / pattern B), decode, interpolate by 16."""
+    import sdrdaemon_amd as sd
+
+    F, R = 3, 32
+    y = signals.mixed(F * 16129, 3)
+    frames = oracle.framer(nb_fec_blocks=R).write(y)
+    rs = np.random.RandomState(2)
+    rxb = np.zeros((F, 128, 512), np.uint8)
+    for f in range(F):
+        allb = np.concatenate([frames[f], oracle.frame_encode(frames[f], R)])
+        lost = set(range(1, 121, 5)) if f != 1 else (set(rs.choice(160, 24, replace=False).tolist()) | {0})
+        rxb[f] = allb[[i for i in range(160) if i not in lost][:128]]
+    for log2 in (4, 0, 6):
+        tx = sd.TxPipe(ctx, 1, log2)
+        iq = np.concatenate([tx.process(rxb[:2]), tx.process(rxb[2:])])
+        assert np.array_equal(iq, oracle.interpolators().interpolate(log2, y)), log2
+
+
+def test_roundtrip_rx_to_tx_full_size_property(ctx):
+    """BASELINE-size property (no oracle in the loop): encode -> erase 24 of 160 -> decode gives
+    back the decimated stream for 64 frames x 4 streams."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    S, F = 4, 16
+    n = F * 16129 * 16
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randint(-32768, 32768, (S, n, 2), generator=g, device="cuda", dtype=torch.int16)
+    rx = sd.RxPipe(ctx, S, log2decim=4, nb_fec=32)
+    frames = rx.process(x)
+    dec = sd.Decimators(ctx, S, 0)
+    y, _ = dec.decimate(4, 2, 16, x)
+    ctx.synchronize()
+    assert frames.shape[:2] == (S, F)
+    keep = [i for i in range(160) if i not in set(range(2, 122, 5))][:128]
+    rxb = frames[:, :, keep].contiguous()
+    payload = sd.fec_decode_frames(ctx, rxb.reshape(S * F, 128, 512))
+    ctx.synchronize()
+    got = payload.reshape(S, F * 16129 * 4).view(torch.int16).reshape(S, F * 16129, 2)
+    assert torch.equal(got, y[:, :F * 16129])
