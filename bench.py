@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- headline metric of BASELINE.json on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload): BASELINE.json configs[2] -- TestSource-shaped 16-bit IQ streams,
+decimate by 16 centred (Decimators::decimate16_cen over IntHalfbandFilterEO1) + UDPSinkFEC
+framing + CM256 128+32 encode -- as 8 independent streams per GPU (configs[4] is exactly this
+at 8 GPUs: 64 streams, 8 per GPU), 2^25 device-rate samples per stream and step, i.e. 2^28
+samples = 1 GiB of int16 IQ per GPU and step, resident in HBM before the timed region.
+A step = one sdrhip_rx_process() call over that batch (decimate -> frame -> encode); the
+streams are continuous across steps (filter state and partial frames carry over).
+
+One JSON line on rank 0; `value` = whole-job M input samples / s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+STREAMS_PER_GPU = 8
+LOG2DECIM, NB_FEC = 4, 32
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic bytes per input sample
+BYTES_DECIM = 4.0 + 4.0 / 16.0                      # kernel K1: read int16 IQ, write 1/16 of it
+BYTES_CONFIG3 = 4.0 + 160.0 * 512.0 / 258064.0      # whole pipe incl. the 160 x 512 B frames
+
+
+def make_input(device, n, seed, kind):
+    g = torch.Generator(device=device).manual_seed(seed)
+    if kind == "noise":  # uniform full-scale int16 (the stress input of BASELINE.md 3.4, worst case for toggling)
+        return torch.randint(-32768, 32768, (n, 2), generator=g, device=device, dtype=torch.int16)
+    # TestSource-like CW (TestSource.cpp:395-422 shape, double precision) + 6 LSB of dither
+    k = torch.arange(n, device=device, dtype=torch.float64)
+    ph = 2.0 * np.pi * k * ((100e3 + 1e3 * seed) / 10e6)
+    a = 3276.8
+    x = torch.stack([torch.round(a * torch.cos(ph)), torch.round(a * torch.sin(ph))], dim=1)
+    x += torch.randint(-3, 4, (n, 2), generator=g, device=device).to(torch.float64)
+    return x.to(torch.int16)
+
+
+def cpu_baseline(budget_s):
+    """Same pipe on ONE host core: the real reference decimator (oracle/_ref, EO1 build of
+    Decimators::decimate16_cen) + the oracle's pshufb CM256 encoder (cm256cc itself is absent:
+    that leg is a port).  Bounded sample, scaled to M samples / s."""
+    import signals
+    from oracle_lib import Oracle, Reference
+
+    orc = Oracle()
+    n = 1 << 22
+    x = signals.noise(n, 4242)
+    use_ref = Reference.available("eo1")
+    if use_ref:
+        dec = Reference("eo1").decimators()
+        kind = "reference"
+        run = lambda reps: dec.decimate_repeat(4, 2, 16, x, reps)  # noqa: E731
+    else:  # pragma: no cover - oracle/_ref travels with the repo
+        dec = orc.decimators(0)
+        kind = "port"
+        run = lambda reps: [dec.decimate(4, 2, 16, x) for _ in range(reps)][-1][0]  # noqa: E731
+    y = run(1)  # warm-up pass
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < budget_s * 0.8:
+        y = run(4)
+        reps += 4
+    t_dec = (time.perf_counter() - t0) / reps  # seconds per 2^22 samples
+    # FEC leg on the frames that 2^22 input samples produce (16 frames + change): time 16 frames
+    y = np.ascontiguousarray(y[:16 * 16129])
+    frames = orc.framer(nb_fec_blocks=NB_FEC).write(y)
+    t1 = time.perf_counter()
+    nfr = 0
+    while time.perf_counter() - t1 < budget_s * 0.2:
+        for f in range(frames.shape[0]):
+            orc.frame_encode(frames[f], NB_FEC)
+        nfr += frames.shape[0]
+    t_fec = (time.perf_counter() - t1) / nfr  # seconds per frame = per 258064 input samples
+    sec_per_sample = t_dec / n + t_fec / 258064.0
+    return {
+        "value": round(1e-6 / sec_per_sample, 3), "unit": "Msamples/s", "cores": 1, "kind": kind,
+        "sample": "%d x 2^22 random full-scale samples through %s decimate16_cen (%.1f Msamples/s alone) + %d frames "
+                  "through the oracle's SSSE3 cm256 128+32 encoder (port; %.2f ms/frame), one thread, serialised" %
+                  (reps, "the reference's compiled" if use_ref else "the oracle's", 1e-6 * n / t_dec, nfr, 1e3 * t_fec),
+        "decimate_only_msps": round(1e-6 * n / t_dec, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-samples", type=int, default=25, help="samples per stream per step (default 2^25)")
+    ap.add_argument("--input", choices=["noise", "testsource"], default="noise")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+    else:
+        dist = None
+        torch.cuda.set_device(local)
+    assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
+
+    import sdrdaemon_amd as sd
+    from sdrdaemon_amd.engine import K_DECIMATE, K_FEC_ENCODE
+
+    dev = torch.device("cuda", local)
+    ctx = sd.Context(local)
+    S, n = STREAMS_PER_GPU, 1 << args.log2_samples
+    # streams are sharded one-per-stream across ranks: global stream id = rank * S + s
+    x = torch.stack([make_input(dev, n, 1000 + rank * S + s, args.input) for s in range(S)])
+    rx = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                   center_frequency_khz=435000, sample_rate=625000)
+    cap = rx.max_frames(n) + 1
+    out = torch.empty((S, cap, 128 + NB_FEC, 512), dtype=torch.uint8, device=dev)
+
+    def step(i):
+        return rx.process(x, tv_sec=i, tv_usec=0, out=out)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    ctx.kernel_timing(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = 0
+    for i in range(args.steps):
+        frames += step(args.warmup + i).shape[1]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    dec_ms, dec_n = ctx.kernel_timing_read(K_DECIMATE)
+    fec_ms, fec_n = ctx.kernel_timing_read(K_FEC_ENCODE)
+    ctx.kernel_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the only collective: 8 bytes, reporting only
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_samples = float(world) * S * n * args.steps
+        value = total_samples / elapsed / 1e6
+        per_launch_samples = float(S) * n
+        avg_ms = dec_ms / max(dec_n, 1)
+        achieved = BYTES_DECIM * per_launch_samples / (avg_ms * 1e-3) / 1e9
+        res = {
+            "metric": "IQ Msamples/s through decim+FEC-encode pipe; bit-exact vs CPU ref",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32",
+            "data": "synthetic: %s, %d streams/GPU (stream id = rank*%d + s), HBM-resident before the timed region" %
+                    ("uniform random full-scale int16 IQ" if args.input == "noise" else "TestSource-like CW A=0.1 + dither", S, S),
+            "config": {"workload": "configs[2] x %d streams/GPU: 10 Msps-shaped int16 IQ, decimate16_cen (EO1) + UDPSinkFEC framing + "
+                                   "CM256 128+32 encode" % S,
+                       "streams_per_gpu": S, "samples_per_stream_per_step": n, "log2decim": LOG2DECIM, "fcpos": "cen",
+                       "nb_fec": NB_FEC, "hb_variant": "EO1", "frames_per_stream_per_step": frames // max(args.steps, 1),
+                       "parallelism": "stream-sharded x%d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "decim_kernel<L=4,cen,pack16,C0=4096>", "launches": dec_n, "avg_launch_ms": round(avg_ms, 4),
+                         "algorithmic_bytes_per_launch": BYTES_DECIM * per_launch_samples,
+                         "pipe_gbps_config3": round(BYTES_CONFIG3 * value * 1e6 / 1e9 / world, 1),
+                         "fec_encode_avg_launch_ms": round(fec_ms / max(fec_n, 1), 4), "fec_encode_launches": fec_n},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            res["gpu_over_cpu_1core"] = round(value / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

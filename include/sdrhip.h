@@ -70,6 +70,15 @@ int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
  * bench.py's roofline object reports). */
 int sdrhip_ctx_timing_begin(sdrhip_ctx *ctx);
 int sdrhip_ctx_timing_end(sdrhip_ctx *ctx, float *elapsed_ms);
+/* Per-kernel-class timing: while enabled, every launch of the class is bracketed by
+ * hipEvents on the context's stream.  _read synchronises, returns the summed duration and
+ * the number of launches since the last read, and clears the log.  Classes: */
+#define SDRHIP_K_DECIMATE 0    /* half-band decimator cascade kernel */
+#define SDRHIP_K_INTERPOLATE 1 /* half-band interpolator cascade kernel */
+#define SDRHIP_K_FEC_ENCODE 2  /* GF(256) matrix apply, encoder rows */
+#define SDRHIP_K_FEC_DECODE 3  /* GF(256) matrix apply, decode matrices */
+int sdrhip_ctx_kernel_timing(sdrhip_ctx *ctx, int enable);
+int sdrhip_ctx_kernel_timing_read(sdrhip_ctx *ctx, int kernel_class, double *total_ms, unsigned *launches);
 
 /* --------------------------------------------------------------- decimators -- */
 /* A bank of `nstreams` independent `Decimators` objects (Decimators.h:32-71): per stream

@@ -24,7 +24,7 @@ UDPSIZE, NB_ORIGINAL, BLOCK_BYTES, SAMPLES_PER_BLOCK, SAMPLES_PER_FRAME = 512, 1
 
 EXPORTS = [
     "sdrhip_last_error", "sdrhip_device_count", "sdrhip_ctx_create", "sdrhip_ctx_destroy", "sdrhip_ctx_synchronize",
-    "sdrhip_ctx_timing_begin", "sdrhip_ctx_timing_end", "sdrhip_decimators_create", "sdrhip_decimators_destroy",
+    "sdrhip_ctx_timing_begin", "sdrhip_ctx_timing_end", "sdrhip_ctx_kernel_timing", "sdrhip_ctx_kernel_timing_read", "sdrhip_decimators_create", "sdrhip_decimators_destroy",
     "sdrhip_decimators_reset", "sdrhip_decimate", "sdrhip_interpolators_create", "sdrhip_interpolators_destroy",
     "sdrhip_interpolators_reset", "sdrhip_interpolate", "sdrhip_cm256_encode", "sdrhip_cm256_decode",
     "sdrhip_fec_encode_frames", "sdrhip_fec_decode_frames", "sdrhip_rx_create", "sdrhip_rx_destroy", "sdrhip_rx_process",
@@ -65,6 +65,8 @@ def load():
     lib.sdrhip_ctx_synchronize.argtypes = [vp]
     lib.sdrhip_ctx_timing_begin.argtypes = [vp]
     lib.sdrhip_ctx_timing_end.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.sdrhip_ctx_kernel_timing.argtypes = [vp, i]
+    lib.sdrhip_ctx_kernel_timing_read.argtypes = [vp, i, C.POINTER(C.c_double), C.POINTER(u)]
     lib.sdrhip_decimators_create.argtypes = [vp, i, i, C.POINTER(vp)]
     lib.sdrhip_decimators_destroy.argtypes = [vp]
     lib.sdrhip_decimators_destroy.restype = None

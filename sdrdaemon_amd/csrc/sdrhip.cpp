@@ -121,6 +121,31 @@ extern "C" int sdrhip_ctx_timing_end(sdrhip_ctx *c, float *ms)
     return SDRHIP_OK;
 }
 
+extern "C" int sdrhip_ctx_kernel_timing(sdrhip_ctx *c, int enable)
+{
+    if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
+    c->ktime_on = enable != 0;
+    return SDRHIP_OK;
+}
+
+extern "C" int sdrhip_ctx_kernel_timing_read(sdrhip_ctx *c, int cls, double *total_ms, unsigned *launches)
+{
+    if (!c || cls < 0 || cls > 3 || !total_ms || !launches) return fail(SDRHIP_EINVAL, "kernel_timing_read: bad argument");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double sum = 0;
+    unsigned n = 0;
+    for (auto &pr : c->kev[cls]) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { sum += ms; ++n; }
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    c->kev[cls].clear();
+    *total_ms = sum;
+    *launches = n;
+    return SDRHIP_OK;
+}
+
 // ------------------------------------------------------------------------------ decimators
 struct sdrhip_decimators {
     sdrhip_ctx *ctx;
@@ -217,7 +242,11 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     plan_decimate((int)L, fcpos, a.n_used, d->nstreams, &a.nsub_per_seg, &a.nseg);
     const bool cen = (fcpos == SDRHIP_FC_CEN);
     const bool pack16 = cen && d->stage0_int16;
-    hipError_t e = launch_decimate((int)L, fcpos, pack16, a, c->stream);
+    hipError_t e;
+    {
+        KTimer kt(c, SDRHIP_K_DECIMATE);
+        e = launch_decimate((int)L, fcpos, pack16, a, c->stream);
+    }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "decimate launch: %s", hipGetErrorString(e));
     d->cur ^= 1;
     d->stage0_int16 = cen; // m_decimator2 now holds raw int16 samples (cen) or rotate-sums (inf/sup)

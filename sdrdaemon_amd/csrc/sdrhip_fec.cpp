@@ -13,7 +13,7 @@ using namespace sdrhip;
 namespace sdrhip {
 
 int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
-                      size_t rec_frame_bytes)
+                      size_t rec_frame_bytes, const int32_t *frame_list_dev, int ngroups)
 {
     if (nframes == 0 || nb_fec <= 0) return SDRHIP_OK;
     GfArgs a;
@@ -23,7 +23,12 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
     a.in_pitch = SDRHIP_UDPSIZE; a.out_pitch = SDRHIP_UDPSIZE; a.in_off = 4; a.out_off = 4;
     a.rows = nb_fec; a.cols = SDRHIP_NB_ORIGINAL; a.coef_per_frame = 0;
     a.nframes = (int)nframes;
-    hipError_t e = launch_gf_apply(a, c->stream);
+    a.frame_list = frame_list_dev; a.ngroups = ngroups;
+    hipError_t e;
+    {
+        KTimer kt(c, SDRHIP_K_FEC_ENCODE);
+        e = launch_gf_apply(a, c->stream);
+    }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec encode launch: %s", hipGetErrorString(e));
     // headers {frameIndex, 128 + r, filler 0} of the recovery super blocks (UDPSinkFEC.cpp:239-243)
     e = launch_fec_headers(frames, frame_bytes, rec, rec_frame_bytes, nb_fec, SDRHIP_NB_ORIGINAL, (int)nframes, c->stream);
@@ -143,7 +148,10 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
     a.nframes = (int)nframes;
     a.frame_list = reinterpret_cast<const int32_t *>(base + o_list);
     a.ngroups = ngroups;
-    e = launch_gf_apply(a, c->stream);
+    {
+        KTimer kt(c, SDRHIP_K_FEC_DECODE);
+        e = launch_gf_apply(a, c->stream);
+    }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec decode launch: %s", hipGetErrorString(e));
     if (block0_out && any_b0) {
         a.out = block0_out; a.out_frame_bytes = SDRHIP_BLOCK_BYTES;

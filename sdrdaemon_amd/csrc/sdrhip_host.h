@@ -5,6 +5,8 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
+#include <vector>
 
 namespace sdrhip {
 
@@ -35,8 +37,9 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
                        size_t out_stride, size_t *n_out);
 // frames/recovery on the device; recovery slots may be interleaved with the frames
 // (rec_frame_bytes = stride between the recovery areas of consecutive frames)
+// frame_list_dev (optional, device): groups of four frame indices (-1 = none), ngroups of them
 int fec_encode_device(sdrhip_ctx *ctx, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
-                      size_t rec_frame_bytes);
+                      size_t rec_frame_bytes, const int32_t *frame_list_dev = nullptr, int ngroups = 0);
 // rx on the device, indices on the host; payload_out / block0_out on the device
 int fec_decode_device(sdrhip_ctx *ctx, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
                       uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out);
@@ -50,4 +53,28 @@ struct sdrhip_ctx {
     uint8_t *gf_tab = nullptr;               // 256 x 32 B multiplier tables (device)
     uint8_t *enc_matrix = nullptr;           // 128 x 128 encode matrix, rows 128..255 (device)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // per-kernel-class timing with hipEvents on `stream` (sdrhip_ctx_kernel_timing)
+    bool ktime_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev[4];
 };
+
+namespace sdrhip {
+// RAII: brackets the launches of one kernel class with events when timing is enabled
+struct KTimer {
+    sdrhip_ctx *c;
+    int cls;
+    hipEvent_t e1 = nullptr;
+    KTimer(sdrhip_ctx *ctx, int kernel_class) : c(ctx), cls(kernel_class)
+    {
+        if (!c->ktime_on) return;
+        hipEvent_t e0 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
+        (void)hipEventRecord(e0, c->stream);
+        c->kev[cls].push_back(std::make_pair(e0, e1));
+    }
+    ~KTimer()
+    {
+        if (e1) (void)hipEventRecord(e1, c->stream);
+    }
+};
+} // namespace sdrhip

@@ -72,7 +72,11 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
     a.state_cur = p->state[p->cur]; a.state_next = p->state[p->cur ^ 1];
     a.nstreams = p->nstreams;
     plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
-    hipError_t e = launch_interpolate(log2interp, a, c->stream);
+    hipError_t e;
+    {
+        KTimer kt(c, SDRHIP_K_INTERPOLATE);
+        e = launch_interpolate(log2interp, a, c->stream);
+    }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "interpolate launch: %s", hipGetErrorString(e));
     p->cur ^= 1;
     return SDRHIP_OK;
@@ -126,6 +130,9 @@ struct sdrhip_rx {
     bool frame_open;          // slot 0 has its meta block (a frame was started)
     uint16_t frame_count;     // m_frameCount of slot 0
     DevBuf meta;              // 24-byte meta record (device)
+    DevBuf flist;             // frame list of the encode launch (device)
+    std::vector<int32_t> flist_host;
+    size_t flist_done = 0, flist_cap = 0;
 };
 
 extern "C" int sdrhip_rx_create(sdrhip_ctx *ctx, int nstreams, const sdrhip_rx_config *cfg, sdrhip_rx **out)
@@ -154,6 +161,7 @@ extern "C" void sdrhip_rx_destroy(sdrhip_rx *rx)
     sdrhip_decimators_destroy(rx->dec);
     rx->work.release();
     rx->meta.release();
+    rx->flist.release();
     delete rx;
 }
 
@@ -248,10 +256,20 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
 
     // ---- FEC over the completed frames of every stream, recovery blocks land behind block 127
     if (done && R > 0) {
-        for (int s = 0; s < S; ++s) { // (one launch per stream keeps the frame stride uniform)
-            uint8_t *fs = work + (size_t)s * stream_bytes;
-            if ((rc = fec_encode_device(c, fs, frame_bytes, done, R, fs + (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE, frame_bytes))) return rc;
+        // one launch for every stream: frame (s, f) is frame s * cap_frames + f of the work area
+        if (rx->flist_done != done || rx->flist_cap != rx->cap_frames) {
+            HIP_TRY(hipStreamSynchronize(c->stream)); // a previous upload may still read flist_host
+            rx->flist_host.clear();
+            for (int s = 0; s < S; ++s)
+                for (size_t f = 0; f < done; ++f) rx->flist_host.push_back((int32_t)(s * rx->cap_frames + f));
+            while (rx->flist_host.size() % 4) rx->flist_host.push_back(-1);
+            if ((rc = rx->flist.reserve(rx->flist_host.size() * 4))) return rc;
+            HIP_TRY(hipMemcpyAsync(rx->flist.p, rx->flist_host.data(), rx->flist_host.size() * 4, hipMemcpyHostToDevice, c->stream));
+            rx->flist_done = done; rx->flist_cap = rx->cap_frames;
         }
+        if ((rc = fec_encode_device(c, work, frame_bytes, (size_t)S * rx->cap_frames, R, work + (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE,
+                                    frame_bytes, rx->flist.as<int32_t>(), (int)(rx->flist_host.size() / 4))))
+            return rc;
     }
     if (done) {
         HIP_TRY(hipMemcpy2DAsync(frames_out, S > 1 ? frame_stride_bytes : done * frame_bytes, work, stream_bytes, done * frame_bytes, S,

@@ -25,6 +25,9 @@ except Exception:  # pragma: no cover
     torch = None
 
 
+K_DECIMATE, K_INTERPOLATE, K_FEC_ENCODE, K_FEC_DECODE = 0, 1, 2, 3
+
+
 def _is_torch(x):
     return torch is not None and isinstance(x, torch.Tensor)
 
@@ -58,6 +61,15 @@ class Context:
         ms = C.c_float(0)
         check(self.lib.sdrhip_ctx_timing_end(self.h, C.byref(ms)))
         return ms.value
+
+    def kernel_timing(self, enable=True):
+        check(self.lib.sdrhip_ctx_kernel_timing(self.h, 1 if enable else 0))
+
+    def kernel_timing_read(self, kernel_class):
+        """-> (total_ms, launches) of the kernel class since the last read (K_* constants)"""
+        ms, n = C.c_double(0), C.c_uint(0)
+        check(self.lib.sdrhip_ctx_kernel_timing_read(self.h, kernel_class, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def close(self):
         if self.h:
@@ -356,8 +368,11 @@ class RxPipe:
         if out is None:
             out = (torch.empty((S, cap, NB_ORIGINAL + self.nb_fec, UDPSIZE), dtype=torch.uint8, device=x.device) if is_t
                    else np.empty((S, cap, NB_ORIGINAL + self.nb_fec, UDPSIZE), np.uint8))
+        if out.shape[1] < cap or out.shape[0] != S:
+            raise ValueError("out must hold (S, >= %d, %d, 512) bytes" % (cap, NB_ORIGINAL + self.nb_fec))
+        stride_bytes = out.shape[1] * fb
         nf = C.c_size_t(0)
-        check(self.ctx.lib.sdrhip_rx_process(self.h, _ptr(x), n, _stride_samples(x), tv_sec, tv_usec, _ptr(out), cap * fb,
+        check(self.ctx.lib.sdrhip_rx_process(self.h, _ptr(x), n, _stride_samples(x), tv_sec, tv_usec, _ptr(out), stride_bytes,
                                              C.byref(nf), MEM_DEVICE if is_t else MEM_HOST))
         out = out[:, :nf.value]
         return out[0] if squeeze else out
