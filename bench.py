@@ -177,7 +177,7 @@ def main():
                        "parallelism": "stream-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "decim_kernel<L=4,cen,pack16,C0=4096>", "launches": dec_n, "avg_launch_ms": round(avg_ms, 4),
+                         "kernel": "decim_kernel<L=4,FC=cen,PACK16>", "launches": dec_n, "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": BYTES_DECIM * per_launch_samples,
                          "pipe_gbps_config3": round(BYTES_CONFIG3 * value * 1e6 / 1e9 / world, 1),
                          "fec_encode_avg_launch_ms": round(fec_ms / max(fec_n, 1), 4), "fec_encode_launches": fec_n},

@@ -4,80 +4,83 @@
 // decimate{2..64}_cen (Decimators.cpp:94-1305) over IntHalfbandFilterEO1/DB<64>::myDecimate
 // (IntHalfbandFilterEO1.h:34-42,100-147 / IntHalfbandFilterDB.h:32-49,79-107).
 //
-// Design (see DESIGN.md "K1"):
+// Design (DESIGN.md "K1"):
 //  * grid = (segments, streams); a 256-thread workgroup walks one segment of one stream in
-//    sub-chunks of C0 first-stage inputs.  All stage inputs live in LDS as four planes per
-//    stage ({I,Q} x {even,odd} input parity, i.e. the polyphase split of the half-band
-//    filter); 32 entries of history sit in front of every plane and are carried from
-//    sub-chunk to sub-chunk, so nothing is recomputed inside a segment.
-//  * output k of a stage = 32-tap FIR over the odd-parity plane + centre tap from the even
-//    plane.  A thread produces R consecutive outputs of one component from a register
-//    window of R+32 plane entries fetched with ds_read_b128 (planes are padded so that the
-//    per-thread stride is an odd number of 16-byte slots: conflict-free).
-//  * the first stage of the centred modes reads the raw int16 samples packed two per dword
-//    and uses v_dot2c_i32_i16 (2 taps per lane-op, exact: |acc| < 2^30); later stages use
-//    v_add_u32 + v_mad_i32_i24 (inputs are |x| <= 2^18, so the 24-bit multiply is exact in
-//    the low 32 bits, i.e. the reference's wrap-around int32 arithmetic).
-//  * segment 0 loads the filter histories from the bank's state; every other segment
-//    rebuilds them by processing 64 * 2^L raw samples before its first sample (>= the
-//    62 * (2^L - 1) samples that reach the last stage's history) and discarding the
-//    outputs.  The workgroup of the last segment stores the new state (double buffered).
+//    passes of 2048 first-stage inputs.  The inputs of every half-band stage live in LDS as
+//    four planes ({even, odd} input parity x {I, Q}: the polyphase split of the filter)
+//    behind 32 entries of history that are carried from invocation to invocation, so nothing
+//    is recomputed inside a segment.
+//  * output k of a stage = 32-tap FIR over the odd plane + centre tap from the even plane.
+//    A thread produces R consecutive outputs of ONE component from a register window of
+//    R + 32 plane entries (ds_read_b128); lanes 2j / 2j+1 own I / Q of the same outputs, the
+//    plane stride is 8 mod 16 LDS slots, so every 16-lane read group is conflict-free.
+//  * multi-rate schedule: stage 0 runs every pass (R = 8), stage s >= 1 runs every 2^(s-1)
+//    passes when its planes hold 512 fresh entries (R = 4): all 256 threads are busy in
+//    every stage, no wave idles while a narrow late stage runs, and the workgroup needs only
+//    ~35 KB of LDS (4 workgroups = 16 waves per CU).
+//  * the first stage of the centred modes reads raw int16 samples packed two per dword and
+//    uses v_dot2c_i32_i16 (2 taps per lane-op, exact: |acc| < 2^30); later stages use
+//    v_add_u32 + v_mad_i32_i24 (stage inputs are |x| <= 2^18, so the 24-bit multiply is exact
+//    in the low 32 bits = the reference's wrap-around int32 arithmetic).
+//  * the next pass's global loads are issued before the current pass is computed.
+//  * segment 0 takes the filter histories from the bank state; every other segment rebuilds
+//    them by running 64 * 2^L raw samples ahead of its first sample (>= the 62 * (2^L - 1)
+//    samples that reach the last stage's history) with stores suppressed.  The workgroup of
+//    the last segment writes the new state (double buffered).
 #include "sdrhip_internal.h"
 
 namespace sdrhip {
 namespace {
 
-constexpr int NT = 256; // threads per workgroup
+constexpr int NT = 256;    // threads per workgroup
+constexpr int P0 = 2048;   // first-stage inputs per pass
+constexpr int FULL = 512;  // fresh entries per plane that trigger a stage s >= 1
+constexpr int HE = 32;     // history entries in front of every plane
 
 typedef short short2_t __attribute__((ext_vector_type(2)));
+typedef int int2_t __attribute__((ext_vector_type(2)));
 typedef int int4_t __attribute__((ext_vector_type(4)));
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 
 // HBFIRFilterTraits<64>::hbCoeffs = (int32_t)(literal * 2^14), HBFilterTraits.cpp:210-228
 constexpr int C64[16] = {-7, 11, -20, 32, -49, 71, -101, 140, -190, 256, -345, 469, -656, 978, -1698, 5201};
-// symmetric 32-tap view: H32(i), i = 0..31 multiplies odd-plane entry k - i
+// symmetric 32-tap view: H32(i) multiplies odd-plane entry k - i
 __host__ __device__ constexpr int H32(int i) { return i < 16 ? C64[i] : C64[31 - i]; }
 __host__ __device__ constexpr unsigned pack_taps(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
 
-__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// plane strides in dwords; all are 32 mod 64 dwords (= 8 mod 16 slots of 16 bytes)
+constexpr int PK0_DW = 16 + 512 + 16; // packed int16 first stage: 32 + 1024 entries, 2 per dword (+ pad)
+constexpr int I0_DW = 32 + 1024;      // int32 first stage
+constexpr int SN_DW = 32 + FULL;      // stages >= 1
 
-// Geometry of one kernel variant.  C0 = first-stage inputs per sub-chunk, NS = half-band
-// stages, PACK16 = first stage reads packed int16 planes.
-template <int C0_, int NS_, bool PACK16_> struct Geo {
-    static constexpr int C0 = C0_, NS = NS_;
-    static constexpr bool PACK16 = PACK16_;
-    static constexpr int n(int s) { return C0 >> (s + 1); } // outputs per component per sub-chunk
-    static constexpr bool last(int s) { return s == NS - 1; }
-    // outputs per thread: the last stage handles both components in one thread (it packs I/Q)
-    static constexpr int R(int s) { return last(s) ? cmax(4, n(s) / NT) : cmax(8, 2 * n(s) / NT); }
-    static constexpr int T(int s) { return last(s) ? n(s) / R(s) : 2 * n(s) / R(s); }
-    static constexpr bool packed(int s) { return PACK16 && s == 0; }
-    static constexpr int histDw(int s) { return packed(s) ? 16 : 32; }
-    static constexpr int newDw(int s) { return packed(s) ? n(s) / 2 : n(s); }
-    static constexpr int blk(int s) { return packed(s) ? R(s) / 2 : R(s); } // dwords per thread block
-    static constexpr int pad(int s) { return ((blk(s) / 4) % 2 == 0) ? 4 : 0; }
-    static constexpr int planeDw(int s) { return (histDw(s) + newDw(s)) / blk(s) * (blk(s) + pad(s)); }
-    static constexpr int stageBase(int s) { return s == 0 ? 0 : stageBase(s - 1) + 4 * planeDw(s - 1); }
-    static constexpr int ldsDw = stageBase(NS);
-    // dword address inside a plane of stage s
-    static constexpr int addr(int s, int d) { return d + pad(s) * (d / blk(s)); }
+template <int NS_, bool PK_> struct Geo {
+    static constexpr int NS = NS_;
+    static constexpr bool PK = PK_;
+    static constexpr int stride(int s) { return s == 0 ? (PK ? PK0_DW : I0_DW) : SN_DW; }
+    static constexpr int base(int s) { return s == 0 ? 0 : base(s - 1) + 4 * stride(s - 1); }
+    static constexpr int ldsDw = base(NS);
+    // plane p = parity * 2 + comp  (E_I, E_Q, O_I, O_Q)
+    static constexpr int plane(int s, int parity, int comp) { return base(s) + (parity * 2 + comp) * stride(s); }
 };
-
-template <class G, int S> __device__ __forceinline__ int plane_addr(int d)
-{
-    return d + G::pad(S) * (d / G::blk(S));
-}
 
 __device__ __forceinline__ int dot2(unsigned a, unsigned taps, int acc)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, taps), acc, false);
 }
 
+// one v_mad_i32_i24 (hipcc otherwise splits the FIR into v_mul_i32_i24 + v_add3_u32 trees,
+// ~25 % more lane-ops).  The tap is wave-uniform: one SGPR operand, within the constant-bus limit.
+__device__ __forceinline__ int mad24(int a, int tap, int acc)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(tap), "v"(acc));
+    return d;
+}
+
 struct OutCtx {
-    int16_t *out;       // stream base
-    size_t out_base;    // index of the sub-chunk's first final output
-    int valid;          // final outputs of this sub-chunk that exist
-    bool store;         // false during warm-up
+    unsigned *out;     // stream base (dwords = IQ samples, or frame area)
+    size_t out_pos;    // index of the next final output of this stream
+    bool store;        // false during warm-up
     int norm, trunk;
     int frame_mode, frame_blocks;
     uint64_t frame_sample_base;
@@ -91,362 +94,346 @@ __device__ __forceinline__ unsigned final_pack(int i, int q, int norm, int trunk
     return ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
 }
 
-__device__ __forceinline__ void store_final(const OutCtx &oc, int k, unsigned v)
+__device__ __forceinline__ void store_one(const OutCtx &oc, size_t k, unsigned v)
 {
     if (!oc.frame_mode) {
-        reinterpret_cast<unsigned *>(oc.out)[oc.out_base + k] = v;
+        oc.out[k] = v;
     } else {
         // UDPSinkFEC::write framing (UDPSinkFEC.cpp:134-155): 127 samples per super block,
         // block 0 of a frame is the meta block
-        uint64_t g = oc.frame_sample_base + oc.out_base + (uint64_t)k;
+        uint64_t g = oc.frame_sample_base + k;
         uint64_t f = g / 16129u;
         unsigned w = (unsigned)(g - f * 16129u);
         unsigned b = w / 127u, i = w - b * 127u;
-        size_t dw = ((size_t)f * oc.frame_blocks + 1 + b) * 128u + 1 + i;
-        reinterpret_cast<unsigned *>(oc.out)[dw] = v;
+        oc.out[((size_t)f * oc.frame_blocks + 1 + b) * 128u + 1 + i] = v;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// one half-band stage over the current sub-chunk
-template <class G, int S> __device__ __forceinline__ void run_stage(int *lds, int tid, int cnt0, int bias, const OutCtx &oc)
+// one invocation of half-band stage S: `valid` outputs exist; results go to the planes of
+// stage S+1 behind `fill_next` fresh entries, or (last stage) to global memory.
+template <class G, int S> __device__ __forceinline__ void run_stage(int *lds, int tid, int valid, int fill_next, int bias, const OutCtx &oc)
 {
-    constexpr int R = G::R(S);
-    constexpr int T = G::T(S);
-    constexpr bool LAST = G::last(S);
-    constexpr bool PK = G::packed(S);
-    constexpr int PLANE = G::planeDw(S);
-    const int valid = cnt0 >> (S + 1); // outputs of this stage that exist in this sub-chunk
-    if (tid >= T) return;
-    const int tl = LAST ? tid : tid % (T / 2);
-    const int comp0 = LAST ? 0 : tid / (T / 2);
-    const int k0 = tl * R;
+    constexpr bool PK = G::PK && S == 0;
+    constexpr bool LAST = (S == G::NS - 1);
+    constexpr int R = (S == 0) ? 8 : 4;
+    const int j = tid >> 1, comp = tid & 1;
+    const int k0 = j * R;
     if (k0 >= valid) return;
-    int *st = lds + G::stageBase(S);
-
-    int res[LAST ? 2 : 1][R];
+    const int *pe = lds + G::plane(S, 0, 0) + comp * G::stride(S);
+    const int *po = lds + G::plane(S, 1, 0) + comp * G::stride(S);
+    int res[R];
+    if constexpr (PK) {
+        // window dword d holds odd-plane buffer entries k0 + 2d, k0 + 2d + 1
+        constexpr int WO = (R + 32) / 2, WE = R / 2 + 4;
+        unsigned wo[WO], we[WE];
 #pragma unroll
-    for (int ci = 0; ci < (LAST ? 2 : 1); ++ci) {
-        const int comp = comp0 + ci;
-        const int *pe = st + (comp * 2 + 0) * PLANE;
-        const int *po = st + (comp * 2 + 1) * PLANE;
-        if constexpr (PK) {
-            // window dword j holds odd-plane buffer entries k0 + 2j, k0 + 2j + 1
-            constexpr int WO = (R + 32) / 2, WE = (R / 2 + 4);
-            unsigned wo[WO], we[WE];
-            const int base = plane_addr<G, S>(k0 / 2);
+        for (int d = 0; d < WO; d += 4) {
+            uint4_t v = *reinterpret_cast<const uint4_t *>(po + k0 / 2 + d);
+            wo[d] = v.x; wo[d + 1] = v.y; wo[d + 2] = v.z; wo[d + 3] = v.w;
+        }
 #pragma unroll
-            for (int j = 0; j < WO; j += 4) {
-                uint4_t v = *reinterpret_cast<const uint4_t *>(po + base + G::addr(S, j));
-                wo[j] = v.x; wo[j + 1] = v.y; wo[j + 2] = v.z; wo[j + 3] = v.w;
+        for (int d = 0; d < WE; d += 4) { // even-plane window starts at buffer entry k0 + 16
+            uint4_t v = *reinterpret_cast<const uint4_t *>(pe + k0 / 2 + 8 + d);
+            we[d] = v.x; we[d + 1] = v.y; we[d + 2] = v.z; we[d + 3] = v.w;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int acc = bias << 13;
+            if (r & 1) { // window entries r+1 .. r+32 = dwords (r+1)/2 ..; entry x <-> tap 32 + r - x
+                acc = dot2(we[(r + 1) / 2], pack_taps(8192, 0), acc);
+#pragma unroll
+                for (int p = 0; p < 16; ++p) acc = dot2(wo[(r + 1) / 2 + p], pack_taps(H32(31 - 2 * p), H32(30 - 2 * p)), acc);
+            } else {
+                acc = dot2(we[r / 2], pack_taps(0, 8192), acc);
+                acc = dot2(wo[r / 2], pack_taps(0, H32(31)), acc);
+#pragma unroll
+                for (int p = 1; p < 16; ++p) acc = dot2(wo[r / 2 + p], pack_taps(H32(32 - 2 * p), H32(31 - 2 * p)), acc);
+                acc = dot2(wo[r / 2 + 16], pack_taps(H32(0), 0), acc);
             }
-            // even-plane window starts at buffer entry k0 + 16 (dword k0/2 + 8)
+            res[r] = acc >> 13;
+        }
+    } else {
+        int wo[R + 32], we[R + 4];
 #pragma unroll
-            for (int j = 0; j < WE; j += 4) {
-                uint4_t v = *reinterpret_cast<const uint4_t *>(pe + base + G::addr(S, 8 + j));
-                we[j] = v.x; we[j + 1] = v.y; we[j + 2] = v.z; we[j + 3] = v.w;
-            }
+        for (int x = 0; x < R + 32; x += 4) {
+            int4_t v = *reinterpret_cast<const int4_t *>(po + k0 + x);
+            wo[x] = v.x; wo[x + 1] = v.y; wo[x + 2] = v.z; wo[x + 3] = v.w;
+        }
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                int acc = bias << 13;
-                if (r & 1) {
-                    // entries r+1 .. r+32 = dwords (r+1)/2 .. (r+1)/2+15 ; entry x <-> tap 32+r-x
-                    acc = dot2(we[(r + 1) / 2], pack_taps(8192, 0), acc);
+        for (int x = 0; x < R + 4; x += 4) {
+            int4_t v = *reinterpret_cast<const int4_t *>(pe + k0 + 16 + x);
+            we[x] = v.x; we[x + 1] = v.y; we[x + 2] = v.z; we[x + 3] = v.w;
+        }
 #pragma unroll
-                    for (int p = 0; p < 16; ++p)
-                        acc = dot2(wo[(r + 1) / 2 + p], pack_taps(H32(31 - 2 * p), H32(30 - 2 * p)), acc);
-                } else {
-                    acc = dot2(we[r / 2], pack_taps(0, 8192), acc);
-                    acc = dot2(wo[r / 2], pack_taps(0, H32(31)), acc);
+        for (int r = 0; r < R; ++r) {
+            // acc = sum c[i] * (s[n-2i] + s[n-62+2i]) + ((s[n-31] + bias) << 13), n = 2k+1
+            int acc = (int)((unsigned)(we[r + 1] + bias) << 13);
 #pragma unroll
-                    for (int p = 1; p < 16; ++p)
-                        acc = dot2(wo[r / 2 + p], pack_taps(H32(32 - 2 * p), H32(31 - 2 * p)), acc);
-                    acc = dot2(wo[r / 2 + 16], pack_taps(H32(0), 0), acc);
-                }
-                res[ci][r] = acc >> 13;
-            }
-        } else {
-            int wo[R + 32], we[R + 4];
-            const int base = plane_addr<G, S>(k0);
-#pragma unroll
-            for (int x = 0; x < R + 32; x += 4) {
-                int4_t v = *reinterpret_cast<const int4_t *>(po + base + G::addr(S, x));
-                wo[x] = v.x; wo[x + 1] = v.y; wo[x + 2] = v.z; wo[x + 3] = v.w;
-            }
-#pragma unroll
-            for (int x = 0; x < R + 4; x += 4) {
-                int4_t v = *reinterpret_cast<const int4_t *>(pe + base + G::addr(S, 16 + x));
-                we[x] = v.x; we[x + 1] = v.y; we[x + 2] = v.z; we[x + 3] = v.w;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                // acc = sum c[i] * (s[n-2i] + s[n-62+2i]) + ((s[n-31] + bias) << 13), n = 2k+1
-                int acc = (int)((unsigned)(we[r + 1] + bias) << 13);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc += __mul24(wo[r + 32 - i] + wo[r + 1 + i], C64[i]);
-                res[ci][r] = acc >> 13;
-            }
+            for (int i = 0; i < 16; ++i) acc = mad24(wo[r + 32 - i] + wo[r + 1 + i], C64[i], acc);
+            res[r] = acc >> 13;
         }
     }
 
     if constexpr (LAST) {
-        if (!oc.store) return;
-        if (!oc.frame_mode && (R % 4 == 0) && k0 + R <= oc.valid) {
-            unsigned *dst = reinterpret_cast<unsigned *>(oc.out) + oc.out_base + k0;
+        // lanes 2j (I) and 2j+1 (Q) hold the same outputs: fetch the partner's values with a
+        // quad-perm DPP move, the I lane packs and stores
+        unsigned o[R];
 #pragma unroll
-            for (int r = 0; r < R; r += 4) {
-                uint4_t v;
-                v.x = final_pack(res[0][r], res[1][r], oc.norm, oc.trunk);
-                v.y = final_pack(res[0][r + 1], res[1][r + 1], oc.norm, oc.trunk);
-                v.z = final_pack(res[0][r + 2], res[1][r + 2], oc.norm, oc.trunk);
-                v.w = final_pack(res[0][r + 3], res[1][r + 3], oc.norm, oc.trunk);
-                *reinterpret_cast<uint4_t *>(dst + r) = v;
-            }
+        for (int r = 0; r < R; ++r) {
+            int other = __builtin_amdgcn_update_dpp(0, res[r], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+            o[r] = final_pack(res[r], other, oc.norm, oc.trunk);
+        }
+        if (comp != 0 || !oc.store) return;
+        const size_t k = oc.out_pos + k0;
+        if (!oc.frame_mode && k0 + R <= valid) {
+#pragma unroll
+            for (int r = 0; r < R; r += 4) *reinterpret_cast<uint4_t *>(oc.out + k + r) = (uint4_t){o[r], o[r + 1], o[r + 2], o[r + 3]};
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (k0 + r < oc.valid) store_final(oc, k0 + r, final_pack(res[0][r], res[1][r], oc.norm, oc.trunk));
+                if (k0 + r < valid) store_one(oc, k + r, o[r]);
         }
     } else {
-        // outputs k0 .. k0+R-1 are inputs k0.. of stage S+1: even -> E plane, odd -> O plane,
-        // plane entry 32 + k/2
-        constexpr int NPL = G::planeDw(S + 1);
-        int *nx = lds + G::stageBase(S + 1) + comp0 * 2 * NPL;
-        const int e0 = 32 + k0 / 2;
-#pragma unroll
-        for (int j = 0; j < R / 2; j += 4) {
-            int4_t ve, vo;
-            ve.x = res[0][2 * j]; ve.y = res[0][2 * j + 2]; ve.z = res[0][2 * j + 4]; ve.w = res[0][2 * j + 6];
-            vo.x = res[0][2 * j + 1]; vo.y = res[0][2 * j + 3]; vo.z = res[0][2 * j + 5]; vo.w = res[0][2 * j + 7];
-            const int a = plane_addr<G, S + 1>(e0 + j);
-            *reinterpret_cast<int4_t *>(nx + a) = ve;
-            *reinterpret_cast<int4_t *>(nx + NPL + a) = vo;
+        // outputs k0.. are inputs k0.. of stage S+1: even -> E plane, odd -> O plane, entry k/2
+        int *ne = lds + G::plane(S + 1, 0, 0) + comp * G::stride(S + 1) + HE + fill_next + k0 / 2;
+        int *no = lds + G::plane(S + 1, 1, 0) + comp * G::stride(S + 1) + HE + fill_next + k0 / 2;
+        if constexpr (R == 8) {
+            *reinterpret_cast<int4_t *>(ne) = (int4_t){res[0], res[2], res[4], res[6]};
+            *reinterpret_cast<int4_t *>(no) = (int4_t){res[1], res[3], res[5], res[7]};
+        } else {
+            *reinterpret_cast<int2_t *>(ne) = (int2_t){res[0], res[2]};
+            *reinterpret_cast<int2_t *>(no) = (int2_t){res[1], res[3]};
         }
     }
 }
 
-template <class G, int S = 0> __device__ __forceinline__ void run_all_stages(int *lds, int tid, int cnt0, int bias, const OutCtx &oc)
+// history of stage S: entries [consumed, consumed + 32) -> [0, 32) of its four planes.
+// One wave moves two planes (read, then write, in lockstep: source and destination may overlap).
+template <class G, int S> __device__ __forceinline__ void slide(int *lds, int tid, int consumed)
 {
-    run_stage<G, S>(lds, tid, cnt0, bias, oc);
-    __syncthreads();
-    if constexpr (S + 1 < G::NS) run_all_stages<G, S + 1>(lds, tid, cnt0, bias, oc);
+    if (tid >= 128) return;
+    const int p = tid >> 5, e = tid & 31;
+    int *pl = lds + G::base(S) + p * G::stride(S);
+    if constexpr (G::PK && S == 0) {
+        short *ps = reinterpret_cast<short *>(pl);
+        const short v = ps[e + consumed]; // (the store below depends on the load: whole wave reads first)
+        ps[e] = v;
+    } else {
+        const int v = pl[e + consumed];
+        pl[e] = v;
+    }
 }
 
-// ------------------------------------------------------------------------------------------
-// history access at entry granularity (entry e of plane p of stage s)
-template <class G> __device__ __forceinline__ int hist_get(const int *lds, int s, int p, int e)
+template <class G, int S> __device__ __forceinline__ void hist_put(int *lds, int p, int e, int v)
 {
-    // runtime stage index: small switch-free arithmetic via constexpr tables is not possible,
-    // so walk the (at most six) stages
-    int v = 0;
-#define SDRHIP_CASE(S_)                                                                                         \
-    if constexpr (S_ < G::NS)                                                                                   \
-        if (s == S_) {                                                                                          \
-            const int *pl = lds + G::stageBase(S_) + p * G::planeDw(S_);                                        \
-            if constexpr (G::packed(S_)) {                                                                      \
-                const short *ps = reinterpret_cast<const short *>(pl);                                          \
-                v = ps[2 * plane_addr<G, S_>(e >> 1) + (e & 1)];                                                \
-            } else {                                                                                            \
-                v = pl[plane_addr<G, S_>(e)];                                                                   \
-            }                                                                                                   \
+    int *pl = lds + G::base(S) + p * G::stride(S);
+    if constexpr (G::PK && S == 0) reinterpret_cast<short *>(pl)[e] = (short)v;
+    else pl[e] = v;
+}
+template <class G, int S> __device__ __forceinline__ int hist_get(const int *lds, int p, int e)
+{
+    const int *pl = lds + G::base(S) + p * G::stride(S);
+    if constexpr (G::PK && S == 0) return reinterpret_cast<const short *>(pl)[e];
+    else return pl[e];
+}
+
+// state word index -> (stage, kernel plane): state plane = comp * 2 + parity, kernel plane = parity * 2 + comp
+template <class G, int S = 0> __device__ __forceinline__ void state_load(int *lds, int tid, const int32_t *st, bool zero)
+{
+    if (tid < 128) {
+        const int sp = tid >> 5, e = tid & 31;
+        const int kp = (sp & 1) * 2 + (sp >> 1);
+        hist_put<G, S>(lds, kp, e, zero ? 0 : st[S * 4 * DEC_HIST + sp * DEC_HIST + e]);
+    }
+    if constexpr (S + 1 < G::NS) state_load<G, S + 1>(lds, tid, st, zero);
+}
+template <class G, int S = 0> __device__ __forceinline__ void state_store(const int *lds, int tid, int32_t *st)
+{
+    if (tid < 128) {
+        const int sp = tid >> 5, e = tid & 31;
+        const int kp = (sp & 1) * 2 + (sp >> 1);
+        st[S * 4 * DEC_HIST + sp * DEC_HIST + e] = hist_get<G, S>(lds, kp, e);
+    }
+    if constexpr (S + 1 < G::NS) state_store<G, S + 1>(lds, tid, st);
+}
+
+// stages 1 .. NS-1 of one pass (each phase = slide of the previous stage + maybe this stage)
+template <class G, int S> __device__ __forceinline__ void later_stages(int *lds, int tid, int (&fill)[6], int consumed_prev, bool flush, int bias, OutCtx &oc)
+{
+    if constexpr (S < G::NS) {
+        slide<G, S - 1>(lds, tid, consumed_prev);
+        fill[S] += consumed_prev / 2;
+        const int have = fill[S];
+        const bool run = have > 0 && (have >= FULL || flush);
+        if (run) {
+            run_stage<G, S>(lds, tid, have, fill[S + 1 < 6 ? S + 1 : 5], bias, oc);
+            if (S == G::NS - 1 && oc.store) oc.out_pos += have;
+            fill[S] = 0;
         }
-    SDRHIP_CASE(0) SDRHIP_CASE(1) SDRHIP_CASE(2) SDRHIP_CASE(3) SDRHIP_CASE(4) SDRHIP_CASE(5)
-#undef SDRHIP_CASE
-    return v;
+        __syncthreads();
+        if (run) later_stages<G, S + 1>(lds, tid, fill, have, flush, bias, oc);
+    } else {
+        slide<G, G::NS - 1>(lds, tid, consumed_prev);
+        __syncthreads();
+    }
 }
 
-template <class G> __device__ __forceinline__ void hist_put(int *lds, int s, int p, int e, int v)
-{
-#define SDRHIP_CASE(S_)                                                                                         \
-    if constexpr (S_ < G::NS)                                                                                   \
-        if (s == S_) {                                                                                          \
-            int *pl = lds + G::stageBase(S_) + p * G::planeDw(S_);                                              \
-            if constexpr (G::packed(S_)) {                                                                      \
-                short *ps = reinterpret_cast<short *>(pl);                                                      \
-                ps[2 * plane_addr<G, S_>(e >> 1) + (e & 1)] = (short)v;                                         \
-            } else {                                                                                            \
-                pl[plane_addr<G, S_>(e)] = v;                                                                   \
-            }                                                                                                   \
-        }
-    SDRHIP_CASE(0) SDRHIP_CASE(1) SDRHIP_CASE(2) SDRHIP_CASE(3) SDRHIP_CASE(4) SDRHIP_CASE(5)
-#undef SDRHIP_CASE
-}
-
-// ------------------------------------------------------------------------------------------
 // FC: 0 inf, 1 sup (fs/4 rotate + sum of four raw samples first), 2 cen
-template <int L, int FC, bool PACK16, int C0> __global__ __launch_bounds__(NT) void decim_kernel(DecimArgs a)
+template <int L, int FC, bool PACK16> __global__ __launch_bounds__(NT) void decim_kernel(DecimArgs a)
 {
     constexpr bool CEN = (FC == 2);
     constexpr int NS = CEN ? L : L - 2;
-    constexpr int RAWSH = CEN ? 0 : 2;           // raw samples per first-stage input = 1 << RAWSH
-    constexpr int CRAW = C0 << RAWSH;            // raw samples per sub-chunk
-    constexpr int WRAW = 64 << L;                // warm-up length in raw samples
-    static_assert(WRAW <= CRAW, "warm-up must fit one sub-chunk");
-    using G = Geo<C0, NS, PACK16>;
-    static_assert(G::ldsDw * 4 <= 160 * 1024, "LDS budget");
-    extern __shared__ __attribute__((aligned(16))) int lds[];
+    constexpr int RAWSH = CEN ? 0 : 2;   // raw samples per first-stage input = 1 << RAWSH
+    constexpr int PRAW = P0 << RAWSH;    // raw samples per pass
+    constexpr int NLD = PRAW / 4 / NT;   // dwordx4 loads per thread and pass
+    constexpr int WRAW = 64 << L;        // warm-up length in raw samples
+    using G = Geo<NS, PACK16>;
+    static_assert(G::ldsDw * 4 <= 64 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) int lds[G::ldsDw];
 
     const int tid = threadIdx.x;
-    const int seg = blockIdx.x;
-    const int stream = blockIdx.y;
-    const int16_t *in = a.in + 2 * (size_t)stream * a.in_stride;
-    const size_t seg_raw = (size_t)a.nsub_per_seg * CRAW;
+    const int seg = blockIdx.x, stream = blockIdx.y;
+    const unsigned *in = reinterpret_cast<const unsigned *>(a.in) + (size_t)stream * a.in_stride;
+    const size_t seg_raw = (size_t)a.nsub_per_seg * PRAW;
     const size_t seg_start = (size_t)seg * seg_raw;
     size_t seg_end = seg_start + seg_raw;
     if (seg_end > a.n_used) seg_end = a.n_used;
-    const bool last_seg = (seg == a.nseg - 1);
 
-    // ---- history init: state for segment 0, zeros (rebuilt by the warm-up) otherwise
     const int32_t *stc = a.state_cur + (size_t)stream * DEC_STATE_WORDS;
-    for (int i = tid; i < NS * 4 * DEC_HIST; i += NT) {
-        const int s = i / (4 * DEC_HIST), p = (i / DEC_HIST) & 3, e = i % DEC_HIST;
-        hist_put<G>(lds, s, p, e, seg == 0 ? stc[i] : 0);
-    }
-    __syncthreads();
+    state_load<G>(lds, tid, stc, seg != 0);
 
     OutCtx oc;
     oc.norm = a.norm; oc.trunk = a.trunk;
     oc.frame_mode = a.frame_mode; oc.frame_blocks = a.frame_blocks; oc.frame_sample_base = a.frame_sample_base;
-    oc.out = a.frame_mode ? reinterpret_cast<int16_t *>(reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride)
-                          : a.out + 2 * (size_t)stream * a.out_stride;
+    oc.out = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
+    oc.out_pos = seg_start >> L;
 
+    int fill[6] = {0, 0, 0, 0, 0, 0};
     bool warm = (seg != 0);
     size_t pos = warm ? seg_start - WRAW : 0;
-    while (pos < seg_end) {
-        const int cnt_raw = warm ? WRAW : (int)((seg_end - pos) < (size_t)CRAW ? (seg_end - pos) : (size_t)CRAW);
+    size_t region_end = warm ? seg_start : seg_end;
+
+    uint4_t ld[NLD];
+    auto issue = [&](size_t p, size_t rend) {
+        const unsigned *src = in + p;
+        const size_t left = rend - p;
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const size_t q = (size_t)tid + (size_t)n * NT;
+            uint4_t v = (uint4_t){0u, 0u, 0u, 0u};
+            if (4 * q + 3 < left) {
+                v = *reinterpret_cast<const uint4_t *>(src + 4 * q);
+            } else if (4 * q < left) { // ragged tail of a call whose length is not a multiple of 4
+                v.x = src[4 * q];
+                if (4 * q + 1 < left) v.y = src[4 * q + 1];
+                if (4 * q + 2 < left) v.z = src[4 * q + 2];
+            }
+            ld[n] = v;
+        }
+    };
+    issue(pos, region_end);
+    __syncthreads();
+
+    while (true) {
+        const size_t left = region_end - pos;
+        const int cnt_raw = left < (size_t)PRAW ? (int)left : PRAW;
         const int cnt0 = cnt_raw >> RAWSH;
-        // ---- load + de-interleave the sub-chunk into the first stage's planes
-        {
-            const unsigned *src = reinterpret_cast<const unsigned *>(in) + pos;
-            int *st = lds;
-            constexpr int P0 = G::planeDw(0);
-#pragma unroll 4
-            for (int q = tid; q < CRAW / 4; q += NT) {
-                if (4 * q >= cnt_raw) break;
-                uint4_t v;
-                if (4 * q + 3 < cnt_raw) {
-                    v = *reinterpret_cast<const uint4_t *>(src + 4 * q);
-                } else { // ragged tail of a call whose length is not a multiple of 4
-                    v.x = src[4 * q];
-                    v.y = (4 * q + 1 < cnt_raw) ? src[4 * q + 1] : 0u;
-                    v.z = (4 * q + 2 < cnt_raw) ? src[4 * q + 2] : 0u;
-                    v.w = 0u;
+        // ---- commit the prefetched samples to the first stage's planes (de-interleave / rotate)
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const int q = tid + n * NT;
+            const uint4_t v = ld[n];
+            if constexpr (CEN && PACK16) {
+                // samples 4q (even), 4q+1 (odd), 4q+2 (even), 4q+3 (odd) as packed int16 pairs
+                lds[G::plane(0, 0, 0) + 16 + q] = (int)__builtin_amdgcn_perm(v.z, v.x, 0x05040100u); // E_I
+                lds[G::plane(0, 0, 1) + 16 + q] = (int)__builtin_amdgcn_perm(v.z, v.x, 0x07060302u); // E_Q
+                lds[G::plane(0, 1, 0) + 16 + q] = (int)__builtin_amdgcn_perm(v.w, v.y, 0x05040100u); // O_I
+                lds[G::plane(0, 1, 1) + 16 + q] = (int)__builtin_amdgcn_perm(v.w, v.y, 0x07060302u); // O_Q
+            } else if constexpr (CEN) {
+                *reinterpret_cast<int2_t *>(&lds[G::plane(0, 0, 0) + HE + 2 * q]) = (int2_t){(int)(short)(v.x & 0xffff), (int)(short)(v.z & 0xffff)};
+                *reinterpret_cast<int2_t *>(&lds[G::plane(0, 0, 1) + HE + 2 * q]) = (int2_t){(int)v.x >> 16, (int)v.z >> 16};
+                *reinterpret_cast<int2_t *>(&lds[G::plane(0, 1, 0) + HE + 2 * q]) = (int2_t){(int)(short)(v.y & 0xffff), (int)(short)(v.w & 0xffff)};
+                *reinterpret_cast<int2_t *>(&lds[G::plane(0, 1, 1) + HE + 2 * q]) = (int2_t){(int)v.y >> 16, (int)v.w >> 16};
+            } else {
+                const int I0 = (short)(v.x & 0xffff), Q0 = (int)v.x >> 16, I1 = (short)(v.y & 0xffff), Q1 = (int)v.y >> 16;
+                const int I2 = (short)(v.z & 0xffff), Q2 = (int)v.z >> 16, I3 = (short)(v.w & 0xffff), Q3 = (int)v.w >> 16;
+                int x, y;
+                if constexpr (FC == 0) { // Decimators.cpp:351-352
+                    x = I0 - Q1 + Q3 - I2; y = Q0 - Q2 + I1 - I3;
+                } else {                 // Decimators.cpp:384-385
+                    x = Q0 - I1 - Q2 + I3; y = -I0 - Q1 + I2 + Q3;
                 }
-                if constexpr (CEN && PACK16) {
-                    // samples 4q (even), 4q+1 (odd), 4q+2 (even), 4q+3 (odd): packed int16 pairs
-                    const int ad = plane_addr<G, 0>(16 + q);
-                    st[0 * P0 + ad] = (int)__builtin_amdgcn_perm(v.z, v.x, 0x05040100u); // I even
-                    st[1 * P0 + ad] = (int)__builtin_amdgcn_perm(v.w, v.y, 0x05040100u); // I odd
-                    st[2 * P0 + ad] = (int)__builtin_amdgcn_perm(v.z, v.x, 0x07060302u); // Q even
-                    st[3 * P0 + ad] = (int)__builtin_amdgcn_perm(v.w, v.y, 0x07060302u); // Q odd
-                } else if constexpr (CEN) {
-                    const int ad = plane_addr<G, 0>(32 + 2 * q); // two consecutive entries, same block
-                    st[0 * P0 + ad] = (int)(short)(v.x & 0xffff); st[0 * P0 + ad + 1] = (int)(short)(v.z & 0xffff);
-                    st[1 * P0 + ad] = (int)(short)(v.y & 0xffff); st[1 * P0 + ad + 1] = (int)(short)(v.w & 0xffff);
-                    st[2 * P0 + ad] = (int)v.x >> 16; st[2 * P0 + ad + 1] = (int)v.z >> 16;
-                    st[3 * P0 + ad] = (int)v.y >> 16; st[3 * P0 + ad + 1] = (int)v.w >> 16;
-                } else {
-                    const int I0 = (short)(v.x & 0xffff), Q0 = (int)v.x >> 16, I1 = (short)(v.y & 0xffff), Q1 = (int)v.y >> 16;
-                    const int I2 = (short)(v.z & 0xffff), Q2 = (int)v.z >> 16, I3 = (short)(v.w & 0xffff), Q3 = (int)v.w >> 16;
-                    int x, y;
-                    if constexpr (FC == 0) { // Decimators.cpp:351-352
-                        x = I0 - Q1 + Q3 - I2; y = Q0 - Q2 + I1 - I3;
-                    } else {                 // Decimators.cpp:384-385
-                        x = Q0 - I1 - Q2 + I3; y = -I0 - Q1 + I2 + Q3;
-                    }
-                    const int ad = plane_addr<G, 0>(32 + (q >> 1));
-                    st[(0 + (q & 1)) * P0 + ad] = x;
-                    st[(2 + (q & 1)) * P0 + ad] = y;
-                }
+                lds[G::plane(0, q & 1, 0) + HE + (q >> 1)] = x;
+                lds[G::plane(0, q & 1, 1) + HE + (q >> 1)] = y;
             }
         }
+        // ---- what comes next, and its loads in flight while this pass computes
+        const size_t next_pos = pos + cnt_raw;
+        const bool flush = next_pos >= region_end;
+        bool more = !flush;
+        size_t n_pos = next_pos, n_end = region_end;
+        if (flush && warm && seg_start < seg_end) { more = true; n_pos = seg_start; n_end = seg_end; }
+        if (more) issue(n_pos, n_end);
         __syncthreads();
 
-        oc.out_base = pos >> L;
-        oc.valid = cnt_raw >> L;
         oc.store = !warm;
-        run_all_stages<G>(lds, tid, cnt0, a.bias, oc); // ends with a barrier
+        const int valid0 = cnt0 >> 1;
+        run_stage<G, 0>(lds, tid, valid0, fill[1], a.bias, oc);
+        if (NS == 1 && oc.store) oc.out_pos += valid0;
+        __syncthreads();
+        later_stages<G, 1>(lds, tid, fill, valid0, flush, a.bias, oc);
 
-        // ---- slide the histories: entries [valid, valid+32) -> [0, 32) of every plane
-        {
-            constexpr int NK = (NS * 4 * DEC_HIST + NT - 1) / NT;
-            int keep[NK];
-#pragma unroll
-            for (int n = 0; n < NK; ++n) {
-                const int i = tid + n * NT;
-                const int s = i / (4 * DEC_HIST), p = (i / DEC_HIST) & 3, e = i % DEC_HIST;
-                keep[n] = (i < NS * 4 * DEC_HIST) ? hist_get<G>(lds, s, p, e + (cnt0 >> (s + 1))) : 0;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int n = 0; n < NK; ++n) {
-                const int i = tid + n * NT;
-                const int s = i / (4 * DEC_HIST), p = (i / DEC_HIST) & 3, e = i % DEC_HIST;
-                if (i < NS * 4 * DEC_HIST) hist_put<G>(lds, s, p, e, keep[n]);
-            }
-            __syncthreads();
-        }
-        pos += cnt_raw;
-        warm = false;
+        if (!more) break;
+        if (flush) { warm = false; region_end = seg_end; }
+        pos = n_pos;
     }
 
     // ---- new filter state (double buffered: other workgroups still read state_cur)
-    if (last_seg) {
+    if (seg == a.nseg - 1) {
         int32_t *stn = a.state_next + (size_t)stream * DEC_STATE_WORDS;
-        for (int i = tid; i < DEC_STAGES * 4 * DEC_HIST; i += NT) {
-            const int s = i / (4 * DEC_HIST), p = (i / DEC_HIST) & 3, e = i % DEC_HIST;
-            stn[i] = (s < NS) ? hist_get<G>(lds, s, p, e) : stc[i];
-        }
+        state_store<G>(lds, tid, stn);
+        for (int i = NS * 4 * DEC_HIST + tid; i < DEC_STAGES * 4 * DEC_HIST; i += NT) stn[i] = stc[i];
     }
 }
 
-template <int L, int FC, bool PACK16, int C0> hipError_t launch_variant(const DecimArgs &a, hipStream_t stream)
+template <int L, int FC, bool PACK16> hipError_t launch_variant(const DecimArgs &a, hipStream_t stream)
 {
-    constexpr bool CEN = (FC == 2);
-    constexpr int NS = CEN ? L : L - 2;
-    using G = Geo<C0, NS, PACK16>;
-    constexpr size_t lds_bytes = (size_t)G::ldsDw * 4;
-    static bool attr_set = false;
-    auto kern = decim_kernel<L, FC, PACK16, C0>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    dim3 grid(a.nseg, a.nstreams);
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds_bytes, stream, a);
+    hipLaunchKernelGGL((decim_kernel<L, FC, PACK16>), dim3(a.nseg, a.nstreams), dim3(NT), 0, stream, a);
     return hipGetLastError();
 }
-
-constexpr int C0_DEFAULT = 4096;
-template <int L> constexpr int c0_for() { return (64 << L) > C0_DEFAULT ? (64 << L) : C0_DEFAULT; }
 
 } // namespace
 
 void plan_decimate(int log2decim, int fcpos, size_t n_used, int nstreams, int *nsub_per_seg, int *nseg)
 {
     const bool cen = (fcpos == 2);
-    (void)log2decim;
-    const size_t craw = cen ? (size_t)C0_DEFAULT : (size_t)C0_DEFAULT * 4;
-    size_t nsub = (n_used + craw - 1) / craw;
-    if (nsub == 0) nsub = 1;
-    // enough workgroups to fill 256 CUs (two resident per CU), but at most 8 sub-chunks of
-    // warm-up-free work per segment once the chip is full
-    size_t per = 8;
-    while (per > 1 && ((nsub + per - 1) / per) * (size_t)nstreams < 2048) per >>= 1;
+    const size_t praw = cen ? (size_t)P0 : (size_t)P0 * 4;
+    size_t npass = (n_used + praw - 1) / praw;
+    if (npass == 0) npass = 1;
+    // a segment is a whole number of schedule periods (2^(NS-2) passes) so that full-rate
+    // stages never flush early; >= 16 passes keep the warm-up (64 * 2^L samples) below ~3 %.
+    const int ns = cen ? log2decim : log2decim - 2;
+    size_t period = (size_t)1 << (ns > 2 ? ns - 2 : 0);
+    size_t per = period < 16 ? 16 : period;
+    // fewer passes per segment when the call is too short to fill 256 CUs x 4 workgroups
+    while (per > period && ((npass + per - 1) / per) * (size_t)nstreams < 2048) per >>= 1;
+    while (per > 1 && ((npass + per - 1) / per) * (size_t)nstreams < 256) per >>= 1;
+    // the warm-up region must not reach before the stream start
+    const size_t wraw = (size_t)64 << log2decim;
+    while (per * praw < wraw) per <<= 1;
     *nsub_per_seg = (int)per;
-    *nseg = (int)((nsub + per - 1) / per);
+    *nseg = (int)((npass + per - 1) / per);
 }
 
 hipError_t launch_decimate(int log2decim, int fcpos, bool pack16, const DecimArgs &a, hipStream_t stream)
 {
 #define SDRHIP_CEN(L_)                                                                                          \
     case L_:                                                                                                    \
-        return pack16 ? launch_variant<L_, 2, true, c0_for<L_>()>(a, stream)                                    \
-                      : launch_variant<L_, 2, false, c0_for<L_>()>(a, stream);
+        return pack16 ? launch_variant<L_, 2, true>(a, stream) : launch_variant<L_, 2, false>(a, stream);
 #define SDRHIP_ROT(L_, FC_)                                                                                     \
     case L_:                                                                                                    \
-        return launch_variant<L_, FC_, false, C0_DEFAULT>(a, stream);
+        return launch_variant<L_, FC_, false>(a, stream);
     if (fcpos == 2) {
         switch (log2decim) {
             SDRHIP_CEN(1) SDRHIP_CEN(2) SDRHIP_CEN(3) SDRHIP_CEN(4) SDRHIP_CEN(5) SDRHIP_CEN(6)

@@ -12,18 +12,19 @@
 // per data dword and reused by every row) and the product is three v_perm_b32 byte-table
 // lookups into the 8+8+4 byte tables of m, XOR-ed together (GF multiplication by a constant
 // is GF(2)-linear).  The 32-byte table of each of the 256 constants lives in LDS and is
-// fetched with uniform-address ds_read_b128/b32 (broadcast), the coefficients of the
-// workgroup's rows sit next to it.  A lane owns 2 x 16 bytes (two frames) of a block column
-// slab, a wave 4 frames x 1 block, and accumulates 8 rows at a time in registers.
+// fetched with uniform-address ds_read_b128/b32 (broadcast); the coefficients of the
+// workgroup's rows sit next to it.  A lane owns one 16-byte slab of a block, a half-wave one
+// 508-byte block, a wave GF_FRAMES_PER_GROUP = 2 frames, and accumulates RB rows at a time in
+// registers; a workgroup = 4 waves = 4 x RB rows of the same frames.
 #include "sdrhip_internal.h"
 
 namespace sdrhip {
 namespace {
 
 constexpr int GF_NT = 256;
-constexpr int RB = 8;         // rows accumulated per wave pass
-constexpr int ROWS_PER_WG = 32;
-constexpr int FRAMES_PER_WG = 4;
+constexpr int RB = 4;                 // rows accumulated per wave
+constexpr int ROWS_PER_WG = 4 * RB;   // 4 waves
+static_assert(GF_FRAMES_PER_GROUP == 2, "lane mapping below assumes one frame per half-wave");
 
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 
@@ -76,14 +77,9 @@ __global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArgs a)
     const int group = blockIdx.x;
     const int row0 = blockIdx.y * ROWS_PER_WG;
 
-    // frames of this group (all share one coefficient matrix)
-    int fr[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        int slot = h * 2 + u;
-        int f = a.frame_list ? a.frame_list[group * FRAMES_PER_WG + slot] : group * FRAMES_PER_WG + slot;
-        fr[u] = (f >= 0 && f < a.nframes) ? f : -1;
-    }
+    // this half-wave's frame (both frames of a group share one coefficient matrix)
+    int fr = a.frame_list ? a.frame_list[group * GF_FRAMES_PER_GROUP + h] : group * GF_FRAMES_PER_GROUP + h;
+    if (fr >= a.nframes) fr = -1;
     const int cm = a.coef_per_frame ? group : 0;
     const int cols = a.cols;
 
@@ -101,37 +97,38 @@ __global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArgs a)
     const int r0 = wave * RB; // this wave's rows inside the workgroup tile
     if (row0 + r0 >= a.rows) return;
 
-    uint4_t acc[RB][2];
+    uint4_t acc[RB];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) acc[rb][u] = (uint4_t){0u, 0u, 0u, 0u};
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = (uint4_t){0u, 0u, 0u, 0u};
 
     const int16_t *csrc = a.col_src ? a.col_src + (size_t)cm * cols : nullptr;
+    const uint8_t *fbase = a.in + (size_t)(fr < 0 ? 0 : fr) * a.in_frame_bytes + a.in_off;
+    uint4_t xn = (uint4_t){0u, 0u, 0u, 0u};
+    {
+        const int sb = csrc ? csrc[0] : 0;
+        if (fr >= 0 && sb >= 0) xn = load_slab(fbase + (size_t)sb * a.in_pitch, l);
+    }
     for (int j = 0; j < cols; ++j) {
-        const int sb = csrc ? csrc[j] : j;
-        Sel s[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            uint4_t x = (uint4_t){0u, 0u, 0u, 0u};
-            if (fr[u] >= 0 && sb >= 0) x = load_slab(a.in + (size_t)fr[u] * a.in_frame_bytes + (size_t)sb * a.in_pitch + a.in_off, l);
-            s[u][0] = make_sel(x.x); s[u][1] = make_sel(x.y); s[u][2] = make_sel(x.z); s[u][3] = make_sel(x.w);
+        const uint4_t x = xn;
+        if (j + 1 < cols) { // next column's slab in flight while this one is multiplied
+            const int sb = csrc ? csrc[j + 1] : j + 1;
+            xn = (uint4_t){0u, 0u, 0u, 0u};
+            if (fr >= 0 && sb >= 0) xn = load_slab(fbase + (size_t)sb * a.in_pitch, l);
         }
+        const Sel s0 = make_sel(x.x), s1 = make_sel(x.y), s2 = make_sel(x.z), s3 = make_sel(x.w);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const unsigned m = coef[(r0 + rb) * 256 + j];
             const uint4_t t = *reinterpret_cast<const uint4_t *>(&tab[m * 8]);
             const unsigned tc = tab[m * 8 + 4];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                acc[rb][u].x ^= mulc(s[u][0], t, tc);
-                acc[rb][u].y ^= mulc(s[u][1], t, tc);
-                acc[rb][u].z ^= mulc(s[u][2], t, tc);
-                acc[rb][u].w ^= mulc(s[u][3], t, tc);
-            }
+            acc[rb].x ^= mulc(s0, t, tc);
+            acc[rb].y ^= mulc(s1, t, tc);
+            acc[rb].z ^= mulc(s2, t, tc);
+            acc[rb].w ^= mulc(s3, t, tc);
         }
     }
 
+    if (fr < 0) return;
     const int16_t *rdst = a.row_dst ? a.row_dst + (size_t)cm * a.rows : nullptr;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -139,9 +136,7 @@ __global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArgs a)
         if (r >= a.rows) break;
         const int db = rdst ? rdst[r] : r;
         if (db < 0) continue;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (fr[u] >= 0) store_slab(a.out + (size_t)fr[u] * a.out_frame_bytes + (size_t)db * a.out_pitch + a.out_off, l, acc[rb][u]);
+        store_slab(a.out + (size_t)fr * a.out_frame_bytes + (size_t)db * a.out_pitch + a.out_off, l, acc[rb]);
     }
 }
 
@@ -176,7 +171,7 @@ __global__ void fec_header_kernel(const uint8_t *frames, size_t in_frame_bytes, 
 hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream)
 {
     if (a.nframes <= 0 || a.rows <= 0) return hipSuccess;
-    const int ngroups = a.frame_list ? a.ngroups : (a.nframes + FRAMES_PER_WG - 1) / FRAMES_PER_WG;
+    const int ngroups = a.frame_list ? a.ngroups : (a.nframes + GF_FRAMES_PER_GROUP - 1) / GF_FRAMES_PER_GROUP;
     if (ngroups <= 0) return hipSuccess;
     dim3 grid(ngroups, (a.rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
     hipLaunchKernelGGL(gf_apply_kernel, grid, dim3(GF_NT), 0, stream, a);

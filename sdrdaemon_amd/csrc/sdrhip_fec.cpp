@@ -107,12 +107,12 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
     }
     if (coefs.empty()) return SDRHIP_OK;
 
-    // ---- groups of four frames sharing a pattern
+    // ---- groups of GF_FRAMES_PER_GROUP frames sharing a pattern
     std::vector<int32_t> frame_list;
     std::vector<int> group_pattern;
     for (size_t pt = 0; pt < members.size(); ++pt)
-        for (size_t i = 0; i < members[pt].size(); i += 4) {
-            for (size_t u = 0; u < 4; ++u) frame_list.push_back(i + u < members[pt].size() ? members[pt][i + u] : -1);
+        for (size_t i = 0; i < members[pt].size(); i += GF_FRAMES_PER_GROUP) {
+            for (size_t u = 0; u < (size_t)GF_FRAMES_PER_GROUP; ++u) frame_list.push_back(i + u < members[pt].size() ? members[pt][i + u] : -1);
             group_pattern.push_back((int)pt);
         }
     const int ngroups = (int)group_pattern.size();

@@ -37,7 +37,7 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
                        size_t out_stride, size_t *n_out);
 // frames/recovery on the device; recovery slots may be interleaved with the frames
 // (rec_frame_bytes = stride between the recovery areas of consecutive frames)
-// frame_list_dev (optional, device): groups of four frame indices (-1 = none), ngroups of them
+// frame_list_dev (optional, device): groups of GF_FRAMES_PER_GROUP frame indices (-1 = none), ngroups of them
 int fec_encode_device(sdrhip_ctx *ctx, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
                       size_t rec_frame_bytes, const int32_t *frame_list_dev = nullptr, int ngroups = 0);
 // rx on the device, indices on the host; payload_out / block0_out on the device

@@ -67,6 +67,9 @@ struct InterpArgs {
 hipError_t launch_interpolate(int log2interp, const InterpArgs &a, hipStream_t stream);
 void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_seg, int *nseg);
 
+// frames are processed in groups that share one coefficient matrix (one frame per half-wave)
+constexpr int GF_FRAMES_PER_GROUP = 2;
+
 // GF(256) matrix apply: out[f][r][:] = XOR_j coef[f or 0][r][j] * in[f][src(j)][:]
 struct GfArgs {
     const uint8_t *in;       // frames: [nframes][in_blocks][in_pitch] bytes
@@ -81,8 +84,8 @@ struct GfArgs {
     const int16_t *row_dst;  // optional [ngroups or 1][rows] destination block index, -1 = skip (else r)
     const int16_t *col_src;  // optional [ngroups or 1][cols] source block index (else j)
     int nframes;
-    // frames are processed in groups of four that share one coefficient matrix (index =
-    // group when coef_per_frame, else 0): frame_list[group * 4 + slot] (or -1), NULL = identity
+    // frames are processed in groups of GF_FRAMES_PER_GROUP that share one coefficient matrix (index =
+    // group when coef_per_frame, else 0): frame_list[group * GF_FRAMES_PER_GROUP + slot] (or -1), NULL = identity
     const int32_t *frame_list;
     int ngroups;
 };

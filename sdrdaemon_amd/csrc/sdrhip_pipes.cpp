@@ -262,13 +262,13 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
             rx->flist_host.clear();
             for (int s = 0; s < S; ++s)
                 for (size_t f = 0; f < done; ++f) rx->flist_host.push_back((int32_t)(s * rx->cap_frames + f));
-            while (rx->flist_host.size() % 4) rx->flist_host.push_back(-1);
+            while (rx->flist_host.size() % GF_FRAMES_PER_GROUP) rx->flist_host.push_back(-1);
             if ((rc = rx->flist.reserve(rx->flist_host.size() * 4))) return rc;
             HIP_TRY(hipMemcpyAsync(rx->flist.p, rx->flist_host.data(), rx->flist_host.size() * 4, hipMemcpyHostToDevice, c->stream));
             rx->flist_done = done; rx->flist_cap = rx->cap_frames;
         }
         if ((rc = fec_encode_device(c, work, frame_bytes, (size_t)S * rx->cap_frames, R, work + (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE,
-                                    frame_bytes, rx->flist.as<int32_t>(), (int)(rx->flist_host.size() / 4))))
+                                    frame_bytes, rx->flist.as<int32_t>(), (int)(rx->flist_host.size() / GF_FRAMES_PER_GROUP))))
             return rc;
     }
     if (done) {
