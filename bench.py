@@ -125,7 +125,9 @@ def main():
     ctx = sd.Context(local)
     S, n = STREAMS_PER_GPU, 1 << args.log2_samples
     # streams are sharded one-per-stream across ranks: global stream id = rank * S + s
-    x = torch.stack([make_input(dev, n, 1000 + rank * S + s, args.input) for s in range(S)])
+    from sdrdaemon_amd import sharding
+
+    x = torch.stack([make_input(dev, n, 1000 + sid, args.input) for sid in sharding.stream_ids(rank, world, S)])
     rx = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
                    center_frequency_khz=435000, sample_rate=625000)
     cap = rx.max_frames(n) + 1
@@ -152,13 +154,10 @@ def main():
     dec_ms, dec_n = ctx.kernel_timing_read(K_DECIMATE)
     fec_ms, fec_n = ctx.kernel_timing_read(K_FEC_ENCODE)
     ctx.kernel_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the only collective: 8 bytes, reporting only
-        elapsed = float(t.item())
+    # the only collectives of the job: MAX of the elapsed time, SUM of the samples (8 bytes each, reporting only)
+    elapsed, total_samples = sharding.aggregate(elapsed, float(S) * n * args.steps, dist, dev)
 
     if rank == 0:
-        total_samples = float(world) * S * n * args.steps
         value = total_samples / elapsed / 1e6
         per_launch_samples = float(S) * n
         avg_ms = dec_ms / max(dec_n, 1)

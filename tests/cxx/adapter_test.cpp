@@ -1,0 +1,103 @@
+// adapter_test.cpp -- exercises the drop-in C++ adapters the way Downsampler::process
+// (Downsampler.cpp:74-162), Upsampler::process (Upsampler.cpp:52-84), UDPSinkFEC::transmitUDP
+// (UDPSinkFEC.cpp:228-256) and SDRdaemonFECBuffer::writeAndRead (.cpp:148-213) use the
+// reference classes.  Reads an int16 IQ file, writes the results; tests/test_gpu_adapters.py
+// compares them with the oracle.
+//   adapter_test in.bin dec.bin int.bin fec.bin
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "Decimators.h"
+#include "Interpolators.h"
+#include "cm256.h"
+
+static std::vector<IQSample> read_iq(const char *path)
+{
+    std::vector<IQSample> v;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return v;
+    std::fseek(f, 0, SEEK_END);
+    long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    v.resize((size_t)n / 4);
+    if (std::fread(v.data(), 4, v.size(), f) != v.size()) v.clear();
+    std::fclose(f);
+    return v;
+}
+
+static void write_bin(const char *path, const void *p, size_t n)
+{
+    FILE *f = std::fopen(path, "wb");
+    std::fwrite(p, 1, n, f);
+    std::fclose(f);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) return 2;
+    IQSampleVector in = read_iq(argv[1]);
+    // --- Rx side: two blocks through decimate16_cen, state carried by the object, then a mode switch
+    Decimators dec;
+    IQSampleVector a(in.begin(), in.begin() + in.size() / 2), b(in.begin() + in.size() / 2, in.end()), o1, o2, o3;
+    unsigned int ss = 16;
+    dec.decimate16_cen(ss, a, o1);
+    ss = 16;
+    dec.decimate16_cen(ss, b, o2);
+    ss = 16;
+    dec.decimate8_inf(ss, a, o3);
+    unsigned int ss4 = 12;
+    IQSampleVector o4;
+    Decimators::decimate4_sup(ss4, a, o4);
+    std::vector<IQSample> dall(o1);
+    dall.insert(dall.end(), o2.begin(), o2.end());
+    dall.insert(dall.end(), o3.begin(), o3.end());
+    dall.insert(dall.end(), o4.begin(), o4.end());
+    write_bin(argv[2], dall.data(), dall.size() * 4);
+    std::printf("sampleSize %u %u\n", ss, ss4);
+    // --- Tx side
+    Interpolators itp;
+    IQSampleVector u1, u2;
+    IQSampleVector head(o1.begin(), o1.begin() + 1000), tail(o1.begin() + 1000, o1.end());
+    itp.interpolate16_cen(head, u1);
+    itp.interpolate16_cen(tail, u2);
+    u1.insert(u1.end(), u2.begin(), u2.end());
+    write_bin(argv[3], u1.data(), u1.size() * 4);
+    // --- FEC: 128 blocks of 508 bytes cut from the input, 32 recovery blocks, lose 24, decode
+    CM256 cm;
+    if (!cm.isInitialized()) return 3;
+    const int K = 128, R = 32, BB = 508;
+    std::vector<unsigned char> orig((size_t)K * BB), rec((size_t)R * BB);
+    std::memcpy(orig.data(), in.data(), orig.size());
+    CM256::cm256_encoder_params p = {K, R, BB};
+    std::vector<CM256::cm256_block> d(K);
+    for (int i = 0; i < K; ++i) { d[i].Block = &orig[(size_t)i * BB]; d[i].Index = (unsigned char)i; }
+    if (cm.cm256_encode(p, d.data(), rec.data())) return 4;
+    std::vector<unsigned char> work(orig);
+    int nrec = 0;
+    for (int i = 0; i < K; ++i) {
+        if (i % 5 == 1 && nrec < 24) { // erased: deliver recovery row nrec in its place, at the END like the wire order
+            ++nrec;
+        }
+    }
+    // survivors in index order, then the recovery blocks (SDRdaemonFECBuffer.cpp:148-163)
+    std::vector<CM256::cm256_block> rxd;
+    std::vector<unsigned char> recw(rec);
+    int used = 0;
+    for (int i = 0; i < K; ++i) {
+        bool erased = (i % 5 == 1) && used < 24;
+        if (erased) { ++used; std::memset(&work[(size_t)i * BB], 0, BB); continue; }
+        CM256::cm256_block bk = {&work[(size_t)i * BB], (unsigned char)i};
+        rxd.push_back(bk);
+    }
+    for (int r = 0; r < used; ++r) { CM256::cm256_block bk = {&recw[(size_t)r * BB], (unsigned char)(K + r)}; rxd.push_back(bk); }
+    CM256::cm256_encoder_params pd = {K, used, BB};
+    if (cm.cm256_decode(pd, rxd.data())) return 5;
+    for (int ir = 0; ir < used; ++ir) { // the fix-up loop of SDRdaemonFECBuffer.cpp:208-213
+        const CM256::cm256_block &bk = rxd[K - used + ir];
+        std::memcpy(&work[(size_t)bk.Index * BB], bk.Block, BB);
+    }
+    std::printf("fec roundtrip %s\n", std::memcmp(work.data(), orig.data(), orig.size()) == 0 ? "OK" : "MISMATCH");
+    write_bin(argv[4], rec.data(), rec.size());
+    return 0;
+}
