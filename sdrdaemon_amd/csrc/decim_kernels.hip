@@ -189,10 +189,28 @@ template <class G, int S> __device__ __forceinline__ void run_stage(int *lds, in
         if (!oc.frame_mode && k0 + R <= valid) {
 #pragma unroll
             for (int r = 0; r < R; r += 4) *reinterpret_cast<uint4_t *>(oc.out + k + r) = (uint4_t){o[r], o[r + 1], o[r + 2], o[r + 3]};
-        } else {
+        } else if (!oc.frame_mode) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (k0 + r < valid) store_one(oc, k + r, o[r]);
+                if (k0 + r < valid) oc.out[k + r] = o[r];
+        } else {
+            // UDPSinkFEC::write framing (UDPSinkFEC.cpp:134-155): 127 samples per super block, block 0
+            // of a frame is the meta block.  One division per thread, then the (frame, block, index)
+            // position advances with carries.
+            const uint64_t g = oc.frame_sample_base + k;
+            const uint64_t f = g / 16129u;
+            const unsigned w = (unsigned)(g - f * 16129u);
+            unsigned b = w / 127u, i = w - b * 127u;
+            size_t dw = ((size_t)f * oc.frame_blocks + 1 + b) * 128u + 1 + i;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (k0 + r < valid) oc.out[dw] = o[r];
+                ++i; ++dw;
+                if (i == 127u) {
+                    i = 0; ++b; dw += 1; // skip the next super block's 4-byte header
+                    if (b == 127u) { b = 0; dw += ((size_t)oc.frame_blocks - 127u) * 128u; } // next frame: skip its recovery blocks and block 0
+                }
+            }
         }
     } else {
         // outputs k0.. are inputs k0.. of stage S+1: even -> E plane, odd -> O plane, entry k/2
@@ -318,16 +336,22 @@ template <int L, int FC, bool PACK16> __global__ __launch_bounds__(NT) void deci
     auto issue = [&](size_t p, size_t rend) {
         const unsigned *src = in + p;
         const size_t left = rend - p;
+        if (left >= (size_t)PRAW) { // full pass (wave-uniform): no per-lane bounds checks
+#pragma unroll
+            for (int n = 0; n < NLD; ++n) ld[n] = *reinterpret_cast<const uint4_t *>(src + 4 * (tid + n * NT));
+            return;
+        }
+        const unsigned rem = (unsigned)left;
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
-            const size_t q = (size_t)tid + (size_t)n * NT;
+            const unsigned q = (unsigned)(tid + n * NT);
             uint4_t v = (uint4_t){0u, 0u, 0u, 0u};
-            if (4 * q + 3 < left) {
+            if (4 * q + 3 < rem) {
                 v = *reinterpret_cast<const uint4_t *>(src + 4 * q);
-            } else if (4 * q < left) { // ragged tail of a call whose length is not a multiple of 4
+            } else if (4 * q < rem) { // ragged tail of a call whose length is not a multiple of 4
                 v.x = src[4 * q];
-                if (4 * q + 1 < left) v.y = src[4 * q + 1];
-                if (4 * q + 2 < left) v.z = src[4 * q + 2];
+                if (4 * q + 1 < rem) v.y = src[4 * q + 1];
+                if (4 * q + 2 < rem) v.z = src[4 * q + 2];
             }
             ld[n] = v;
         }
@@ -415,7 +439,7 @@ void plan_decimate(int log2decim, int fcpos, size_t n_used, int nstreams, int *n
     // stages never flush early; >= 16 passes keep the warm-up (64 * 2^L samples) below ~3 %.
     const int ns = cen ? log2decim : log2decim - 2;
     size_t period = (size_t)1 << (ns > 2 ? ns - 2 : 0);
-    size_t per = period < 16 ? 16 : period;
+    size_t per = period < 32 ? 32 : period; // warm-up = 64 * 2^L of 32 * 2048 samples: 1.6 % at L = 4
     // fewer passes per segment when the call is too short to fill 256 CUs x 4 workgroups
     while (per > period && ((npass + per - 1) / per) * (size_t)nstreams < 2048) per >>= 1;
     while (per > 1 && ((npass + per - 1) / per) * (size_t)nstreams < 256) per >>= 1;

@@ -9,13 +9,17 @@
 // truncation at the end.  interpolate64_cen is reproduced as the reference has it: five
 // stages and 32 zero samples after every 32 outputs (Interpolators.cpp:363-606).
 //
-// Same structure as the decimator kernel: grid = (segments, streams); a 256-thread
-// workgroup walks its segment in sub-chunks of CI inputs; every stage's inputs sit in LDS
-// (I and Q planes, int32) behind 32 entries of history that are carried between sub-chunks;
-// a thread produces the 2R outputs of R consecutive inputs of one component from a register
-// window of R + O/2 entries; the last stage handles both components, packs int16 I/Q and
-// stores 16-byte vectors.  Segment 0 takes the histories from the bank state, other
-// segments rebuild them from the 64 preceding inputs (the cascade's memory is 43 inputs).
+// Design (DESIGN.md "K5"), the mirror image of the decimator kernel:
+//  * grid = (segments, streams); a 256-thread workgroup walks its segment in macro-cycles of
+//    512 inputs.  The inputs of every stage sit in LDS (I and Q planes, int32, plane stride
+//    8 mod 16 slots) behind 32 entries of history.
+//  * the cascade is an expanding tree, walked depth first: one invocation of stage s
+//    (512 inputs) feeds two invocations of stage s+1, so every invocation keeps all 256
+//    threads busy: lanes 2j / 2j+1 compute the 8 outputs of 4 consecutive inputs of I / Q;
+//    the last stage takes 1024 inputs per invocation and handles both components per thread
+//    so that it can pack int16 I/Q and store 2 x 16 bytes per thread without a lane exchange.
+//  * segment 0 takes the histories from the bank state, other segments rebuild them from the
+//    64 preceding inputs (the cascade's memory is 43 inputs) with stores suppressed.
 #include "sdrhip_internal.h"
 
 namespace sdrhip {
@@ -24,6 +28,7 @@ namespace {
 constexpr int NT = 256;
 constexpr int HIST = 32;
 constexpr int WARM = 64;
+constexpr int MC = 512; // inputs per macro-cycle (1024 when the cascade has a single stage)
 
 typedef int int4_t __attribute__((ext_vector_type(4)));
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
@@ -33,47 +38,71 @@ constexpr int T64[16] = {-7, 11, -20, 32, -49, 71, -101, 140, -190, 256, -345, 4
 constexpr int T32[8] = {-30, 63, -135, 261, -469, 830, -1605, 5176};
 constexpr int T16[4] = {-85, 380, -1246, 5041};
 
-__host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ constexpr int stage_order(int s) { return s == 0 ? 64 : (s == 1 ? 32 : 16); }
 __host__ __device__ constexpr int tap(int order, int i) { return order == 64 ? T64[i] : (order == 32 ? T32[i] : T16[i]); }
 
-template <int CI_, int NS_> struct IGeo {
-    static constexpr int CI = CI_, NS = NS_;
-    static constexpr int n(int s) { return CI << s; } // inputs of stage s per component per sub-chunk
-    static constexpr bool last(int s) { return s == NS - 1; }
-    static constexpr int R(int s) { return last(s) ? imax(4, n(s) / NT) : imax(8, 2 * n(s) / NT); }
-    static constexpr int T(int s) { return last(s) ? n(s) / R(s) : 2 * n(s) / R(s); }
-    static constexpr int planeDw(int s) { return HIST + n(s); }
-    static constexpr int stageBase(int s) { return s == 0 ? 0 : stageBase(s - 1) + 2 * planeDw(s - 1); }
-    static constexpr int ldsDw = stageBase(NS);
+__device__ __forceinline__ int mad24(int a, int t, int acc)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(t), "v"(acc));
+    return d;
+}
+
+template <int NS_> struct IGeo {
+    static constexpr int NS = NS_;
+    static constexpr int mc = (NS == 1) ? 1024 : MC;                                  // inputs per macro-cycle
+    static constexpr int cap(int s) { return s == 0 ? mc : 1024; }                     // fresh entries a stage buffer holds
+    static constexpr int stride(int s) { return HIST + cap(s); }                       // 544 / 1056 dwords: 8 mod 16 slots
+    static constexpr int base(int s) { return s == 0 ? 0 : base(s - 1) + 2 * stride(s - 1); }
+    static constexpr int ldsDw = base(NS);
 };
 
 struct IOut {
-    int16_t *out;
-    size_t out_base; // first output sample index of this sub-chunk
-    size_t out_limit; // outputs of this stream that exist
+    unsigned *out;
+    size_t out_pos; // chain output index of the next final output of this stream
     bool store;
-    bool stuff64;    // interpolate64_cen layout
+    bool stuff64;   // interpolate64_cen layout
 };
 
-template <class G, int S> __device__ __forceinline__ void istage(int *lds, int tid, int cnt, const IOut &oc)
+// one invocation of a non-last stage: `valid` inputs at buffer offset in_off -> 2 * valid entries
+// at the start of the next stage's buffer
+template <class G, int S> __device__ __forceinline__ void istage(int *lds, int tid, int in_off, int valid)
 {
-    constexpr int R = G::R(S), T = G::T(S);
-    constexpr bool LAST = G::last(S);
-    constexpr int O = stage_order(S), K = O / 4, S2 = O / 2;
-    constexpr int PLANE = G::planeDw(S);
-    const int valid = cnt << S; // inputs of this stage that exist in this sub-chunk
-    if (tid >= T) return;
-    const int tl = LAST ? tid : tid % (T / 2);
-    const int comp0 = LAST ? 0 : tid / (T / 2);
-    const int m0 = tl * R;
+    constexpr int O = stage_order(S), K = O / 4, S2 = O / 2, R = 4;
+    const int j = tid >> 1, comp = tid & 1;
+    const int m0 = j * R;
     if (m0 >= valid) return;
-    int *st = lds + G::stageBase(S);
-
-    int ev[LAST ? 2 : 1][R], od[LAST ? 2 : 1][R];
+    const int *pl = lds + G::base(S) + comp * G::stride(S) + HIST + in_off + m0 - S2; // window x <-> u[m0 - O/2 + x]
+    int w[R + S2];
 #pragma unroll
-    for (int ci = 0; ci < (LAST ? 2 : 1); ++ci) {
-        const int *pl = st + (comp0 + ci) * PLANE + HIST + m0 - S2; // window entry x <-> u[m0 - O/2 + x]
+    for (int x = 0; x < R + S2; x += 4) {
+        int4_t v = *reinterpret_cast<const int4_t *>(pl + x);
+        w[x] = v.x; w[x + 1] = v.y; w[x + 2] = v.z; w[x + 3] = v.w;
+    }
+    int o[2 * R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) acc = mad24(w[r + 1 + i] + w[r + S2 - i], tap(O, i), acc);
+        o[2 * r] = w[r + K]; // u[m - O/4]
+        o[2 * r + 1] = acc >> 13;
+    }
+    int *nx = lds + G::base(S + 1) + comp * G::stride(S + 1) + HIST + 2 * m0;
+    *reinterpret_cast<int4_t *>(nx) = (int4_t){o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<int4_t *>(nx + 4) = (int4_t){o[4], o[5], o[6], o[7]};
+}
+
+// the last stage: both components per thread, int16 packing, 2 x 16-byte stores
+template <class G, int S> __device__ __forceinline__ void istage_last(int *lds, int tid, int in_off, int valid, const IOut &oc)
+{
+    constexpr int O = stage_order(S), K = O / 4, S2 = O / 2, R = 4;
+    const int m0 = tid * R;
+    if (m0 >= valid || !oc.store) return;
+    int o[2][2 * R];
+#pragma unroll
+    for (int comp = 0; comp < 2; ++comp) {
+        const int *pl = lds + G::base(S) + comp * G::stride(S) + HIST + in_off + m0 - S2;
         int w[R + S2];
 #pragma unroll
         for (int x = 0; x < R + S2; x += 4) {
@@ -84,70 +113,85 @@ template <class G, int S> __device__ __forceinline__ void istage(int *lds, int t
         for (int r = 0; r < R; ++r) {
             int acc = 0;
 #pragma unroll
-            for (int i = 0; i < K; ++i) acc += __mul24(w[r + 1 + i] + w[r + S2 - i], tap(O, i));
-            ev[ci][r] = w[r + K + 0 + (S2 - 2 * K)]; // u[m - K] <-> x = r + O/2 - K
-            od[ci][r] = acc >> 13;
+            for (int i = 0; i < K; ++i) acc = mad24(w[r + 1 + i] + w[r + S2 - i], tap(O, i), acc);
+            o[comp][2 * r] = w[r + K];
+            o[comp][2 * r + 1] = acc >> 13;
         }
     }
-    if constexpr (LAST) {
-        if (!oc.store) return;
-        unsigned o[2 * R];
+    unsigned pk[2 * R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            o[2 * r] = ((unsigned)ev[0][r] & 0xffffu) | ((unsigned)ev[1][r] << 16);
-            o[2 * r + 1] = ((unsigned)od[0][r] & 0xffffu) | ((unsigned)od[1][r] << 16);
-        }
-        size_t idx = oc.out_base + 2 * (size_t)m0; // chain output index
-        if (oc.stuff64) idx = (idx >> 5) * 64 + (idx & 31);
-        unsigned *dst = reinterpret_cast<unsigned *>(oc.out) + idx;
-        if (m0 + R <= valid) {
-#pragma unroll
-            for (int j = 0; j < 2 * R; j += 4) *reinterpret_cast<uint4_t *>(dst + j) = (uint4_t){o[j], o[j + 1], o[j + 2], o[j + 3]};
-            if (oc.stuff64) {
-#pragma unroll
-                for (int j = 0; j < 2 * R; j += 4) *reinterpret_cast<uint4_t *>(dst + 32 + j) = (uint4_t){0u, 0u, 0u, 0u};
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2 * R; ++j)
-                if (m0 + j / 2 < valid) {
-                    dst[j] = o[j];
-                    if (oc.stuff64) dst[32 + j] = 0u;
-                }
+    for (int q = 0; q < 2 * R; ++q) pk[q] = __builtin_amdgcn_perm((unsigned)o[1][q], (unsigned)o[0][q], 0x05040100u); // (I lo16, Q lo16)
+    size_t idx = oc.out_pos + 2 * (size_t)m0; // chain output index
+    if (oc.stuff64) idx = (idx >> 5) * 64 + (idx & 31);
+    unsigned *dst = oc.out + idx;
+    if (m0 + R <= valid) {
+        *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<uint4_t *>(dst + 4) = (uint4_t){pk[4], pk[5], pk[6], pk[7]};
+        if (oc.stuff64) {
+            *reinterpret_cast<uint4_t *>(dst + 32) = (uint4_t){0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint4_t *>(dst + 36) = (uint4_t){0u, 0u, 0u, 0u};
         }
     } else {
-        int *nx = lds + G::stageBase(S + 1) + comp0 * G::planeDw(S + 1) + HIST + 2 * m0;
 #pragma unroll
-        for (int r = 0; r < R; r += 2)
-            *reinterpret_cast<int4_t *>(nx + 2 * r) = (int4_t){ev[0][r], od[0][r], ev[0][r + 1], od[0][r + 1]};
+        for (int q = 0; q < 2 * R; ++q)
+            if (m0 + q / 2 < valid) {
+                dst[q] = pk[q];
+                if (oc.stuff64) dst[32 + q] = 0u;
+            }
     }
 }
 
-template <class G, int S = 0> __device__ __forceinline__ void irun(int *lds, int tid, int cnt, const IOut &oc)
+// history of stage S: entries [consumed, consumed + 32) -> [0, 32) of both planes (one wave:
+// the whole wave reads before it writes, source and destination may overlap)
+template <class G, int S> __device__ __forceinline__ void slide(int *lds, int tid, int consumed)
 {
-    istage<G, S>(lds, tid, cnt, oc);
-    __syncthreads();
-    if constexpr (S + 1 < G::NS) irun<G, S + 1>(lds, tid, cnt, oc);
+    if (tid >= 64) return;
+    int *pl = lds + G::base(S) + (tid >> 5) * G::stride(S);
+    const int e = tid & 31;
+    const int v = pl[HIST + consumed - HIST + e];
+    pl[e] = v;
 }
 
-template <class G> __device__ __forceinline__ int *hist_ptr(int *lds, int s, int comp, int e)
+// depth-first walk: stage S consumes `valid` inputs at in_off of its buffer
+template <class G, int S> __device__ __forceinline__ void descend(int *lds, int tid, int in_off, int valid, IOut &oc)
 {
-    int *p = lds;
-#define SDRHIP_ICASE(S_)                                                                                        \
-    if constexpr (S_ < G::NS)                                                                                   \
-        if (s == S_) p = lds + G::stageBase(S_) + comp * G::planeDw(S_) + e;
-    SDRHIP_ICASE(0) SDRHIP_ICASE(1) SDRHIP_ICASE(2) SDRHIP_ICASE(3) SDRHIP_ICASE(4)
-#undef SDRHIP_ICASE
-    return p;
+    if constexpr (S == G::NS - 1) {
+        istage_last<G, S>(lds, tid, in_off, valid, oc);
+        if (oc.store) oc.out_pos += 2 * (size_t)valid;
+        __syncthreads();
+    } else {
+        istage<G, S>(lds, tid, in_off, valid);
+        __syncthreads();
+        const int n = 2 * valid;
+        if constexpr (S + 1 == G::NS - 1) {
+            descend<G, S + 1>(lds, tid, 0, n, oc);
+        } else {
+            descend<G, S + 1>(lds, tid, 0, n < MC ? n : MC, oc);
+            if (n > MC) descend<G, S + 1>(lds, tid, MC, n - MC, oc);
+        }
+        slide<G, S + 1>(lds, tid, n);
+        __syncthreads();
+    }
+}
+
+template <class G, int S = 0> __device__ __forceinline__ void state_load(int *lds, int tid, const int32_t *st, bool zero)
+{
+    if (tid < 64) lds[G::base(S) + (tid >> 5) * G::stride(S) + (tid & 31)] = zero ? 0 : st[S * 2 * INT_HIST + tid];
+    if constexpr (S + 1 < G::NS) state_load<G, S + 1>(lds, tid, st, zero);
+}
+template <class G, int S = 0> __device__ __forceinline__ void state_store(const int *lds, int tid, int32_t *st)
+{
+    if (tid < 64) st[S * 2 * INT_HIST + tid] = lds[G::base(S) + (tid >> 5) * G::stride(S) + (tid & 31)];
+    if constexpr (S + 1 < G::NS) state_store<G, S + 1>(lds, tid, st);
 }
 
 // L = log2 interpolation (6 = the reference's 5-stage + zero stuffing variant)
-template <int L, int CI> __global__ __launch_bounds__(NT) void interp_kernel(InterpArgs a)
+template <int L> __global__ __launch_bounds__(NT) void interp_kernel(InterpArgs a)
 {
     constexpr int NS = (L == 6) ? 5 : L;
-    using G = IGeo<CI, NS>;
+    using G = IGeo<NS>;
+    constexpr int CI = G::mc;
     static_assert(G::ldsDw * 4 <= 64 * 1024, "LDS budget");
-    static_assert(WARM <= CI, "warm-up must fit one sub-chunk");
     __shared__ __attribute__((aligned(16))) int lds[G::ldsDw];
 
     const int tid = threadIdx.x;
@@ -157,69 +201,62 @@ template <int L, int CI> __global__ __launch_bounds__(NT) void interp_kernel(Int
     const size_t seg_start = (size_t)seg * seg_len;
     size_t seg_end = seg_start + seg_len;
     if (seg_end > a.n_in) seg_end = a.n_in;
-    const bool last_seg = (seg == a.nseg - 1);
 
     const int32_t *stc = a.state_cur + (size_t)stream * INT_STATE_WORDS;
-    for (int i = tid; i < NS * 2 * HIST; i += NT) {
-        const int s = i / (2 * HIST), comp = (i / HIST) & 1, e = i % HIST;
-        *hist_ptr<G>(lds, s, comp, e) = (seg == 0) ? stc[i] : 0;
-    }
-    __syncthreads();
+    state_load<G>(lds, tid, stc, seg != 0);
 
     IOut oc;
-    oc.out = a.out + 2 * (size_t)stream * a.out_stride;
+    oc.out = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
     oc.stuff64 = (L == 6);
-    oc.out_limit = a.n_in << L;
+    oc.out_pos = seg_start << NS;
 
     bool warm = (seg != 0);
     size_t pos = warm ? seg_start - WARM : 0;
-    while (pos < seg_end) {
-        const int cnt = warm ? WARM : (int)((seg_end - pos) < (size_t)CI ? (seg_end - pos) : (size_t)CI);
-        for (int m = tid; m < cnt; m += NT) {
-            const unsigned v = in[pos + m];
-            lds[G::stageBase(0) + HIST + m] = (int)(short)(v & 0xffffu);
-            lds[G::stageBase(0) + G::planeDw(0) + HIST + m] = (int)v >> 16;
+    unsigned ldv[CI / NT];
+    auto issue = [&](size_t p, int cnt) {
+#pragma unroll
+        for (int n = 0; n < CI / NT; ++n) {
+            const int m = tid + n * NT;
+            ldv[n] = (m < cnt) ? in[p + m] : 0u;
+        }
+    };
+    int cnt = warm ? WARM : (int)((seg_end - pos) < (size_t)CI ? (seg_end - pos) : (size_t)CI);
+    issue(pos, cnt);
+    __syncthreads();
+    while (true) {
+#pragma unroll
+        for (int n = 0; n < CI / NT; ++n) {
+            const int m = tid + n * NT;
+            lds[G::base(0) + HIST + m] = (int)(short)(ldv[n] & 0xffffu);
+            lds[G::base(0) + G::stride(0) + HIST + m] = (int)ldv[n] >> 16;
+        }
+        const size_t next_pos = pos + cnt;
+        const bool more = next_pos < seg_end;
+        int next_cnt = 0;
+        if (more) {
+            next_cnt = (int)((seg_end - next_pos) < (size_t)CI ? (seg_end - next_pos) : (size_t)CI);
+            issue(next_pos, next_cnt); // in flight while this macro-cycle computes
         }
         __syncthreads();
-        oc.out_base = pos << NS;
         oc.store = !warm;
-        irun<G>(lds, tid, cnt, oc);
-        // slide the histories: entries [valid, valid + 32) -> [0, 32)
-        {
-            constexpr int NK = (NS * 2 * HIST + NT - 1) / NT;
-            int keep[NK];
-#pragma unroll
-            for (int n = 0; n < NK; ++n) {
-                const int i = tid + n * NT;
-                const int s = i / (2 * HIST), comp = (i / HIST) & 1, e = i % HIST;
-                keep[n] = (i < NS * 2 * HIST) ? *hist_ptr<G>(lds, s, comp, e + (cnt << s)) : 0;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int n = 0; n < NK; ++n) {
-                const int i = tid + n * NT;
-                const int s = i / (2 * HIST), comp = (i / HIST) & 1, e = i % HIST;
-                if (i < NS * 2 * HIST) *hist_ptr<G>(lds, s, comp, e) = keep[n];
-            }
-            __syncthreads();
-        }
-        pos += cnt;
+        descend<G, 0>(lds, tid, 0, cnt, oc);
+        slide<G, 0>(lds, tid, cnt);
+        __syncthreads();
+        if (!more) break;
+        pos = next_pos;
+        cnt = next_cnt;
         warm = false;
     }
-    if (last_seg) {
+    if (seg == a.nseg - 1) {
         int32_t *stn = a.state_next + (size_t)stream * INT_STATE_WORDS;
-        for (int i = tid; i < INT_STAGES * 2 * HIST; i += NT) {
-            const int s = i / (2 * HIST), comp = (i / HIST) & 1, e = i % HIST;
-            stn[i] = (s < NS) ? *hist_ptr<G>(lds, s, comp, e) : stc[i];
-        }
+        state_store<G>(lds, tid, stn);
+        for (int i = NS * 2 * INT_HIST + tid; i < INT_STAGES * 2 * INT_HIST; i += NT) stn[i] = stc[i];
     }
 }
 
-template <int L> constexpr int ci_for() { return L == 1 ? 2048 : (L == 2 ? 1024 : (L == 3 ? 512 : (L == 4 ? 256 : 128))); }
-
 template <int L> hipError_t launch_l(const InterpArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((interp_kernel<L, ci_for<L>()>), dim3(a.nseg, a.nstreams), dim3(NT), 0, stream, a);
+    hipLaunchKernelGGL((interp_kernel<L>), dim3(a.nseg, a.nstreams), dim3(NT), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -227,10 +264,10 @@ template <int L> hipError_t launch_l(const InterpArgs &a, hipStream_t stream)
 
 void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_seg, int *nseg)
 {
-    const size_t ci = log2interp == 1 ? 2048 : (log2interp == 2 ? 1024 : (log2interp == 3 ? 512 : (log2interp == 4 ? 256 : 128)));
+    const size_t ci = log2interp == 1 ? 1024 : MC;
     size_t nsub = (n_in + ci - 1) / ci;
     if (nsub == 0) nsub = 1;
-    size_t per = 16; // warm-up is 64 inputs: 16 sub-chunks per segment keep its cost below 3 %
+    size_t per = 16; // warm-up is 64 inputs: 16 macro-cycles per segment keep its cost below 1 %
     while (per > 1 && ((nsub + per - 1) / per) * (size_t)nstreams < 2048) per >>= 1;
     *nsub_per_seg = (int)per;
     *nseg = (int)((nsub + per - 1) / per);

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Per-kernel timings on the GPU box (hipEvent kernel-class timers of libsdrhip.so).
+usage: python tools/bench_kernels.py [decim] [interp] [fec]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import sdrdaemon_amd as sd  # noqa: E402
+from sdrdaemon_amd.engine import K_DECIMATE, K_FEC_DECODE, K_FEC_ENCODE, K_INTERPOLATE  # noqa: E402
+
+what = sys.argv[1:] or ["decim", "interp", "fec"]
+ctx = sd.Context(0)
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev).manual_seed(1)
+S = 8
+
+
+def timed(cls, fn, reps=5):
+    fn()
+    ctx.synchronize()
+    ctx.kernel_timing(True)
+    for _ in range(reps):
+        fn()
+    ms, n = ctx.kernel_timing_read(cls)
+    ctx.kernel_timing(False)
+    return ms / max(n, 1)
+
+
+if "decim" in what:
+    n = 1 << 24
+    x = torch.randint(-32768, 32768, (S, n, 2), generator=g, device=dev, dtype=torch.int16)
+    for fc, name in ((2, "cen"), (0, "inf"), (1, "sup")):
+        for L in range(1, 7):
+            if fc != 2 and L < 3:
+                continue
+            d = sd.Decimators(ctx, S, 0)
+            out = torch.empty((S, n >> L, 2), dtype=torch.int16, device=dev)
+            ms = timed(K_DECIMATE, lambda: d.decimate(L, fc, 16, x, out=out))
+            gs = S * n / ms / 1e6
+            print("decimate%-2d_%s  %8.3f ms  %8.1f Gsamples/s in  %7.1f GB/s" % (1 << L, name, ms, gs, gs * (4 + 4 / (1 << L))))
+    del x
+if "interp" in what:
+    for L in range(1, 7):
+        n = (1 << 26) >> L
+        x = torch.randint(-32768, 32768, (S, n, 2), generator=g, device=dev, dtype=torch.int16)
+        u = sd.Interpolators(ctx, S)
+        out = torch.empty((S, n << L, 2), dtype=torch.int16, device=dev)
+        ms = timed(K_INTERPOLATE, lambda: u.interpolate(L, x, out=out))
+        go = S * (n << L) / ms / 1e6
+        print("interpolate%-2d_cen  %8.3f ms  %8.1f Gsamples/s out  %7.1f GB/s" % (1 << L, ms, go, go * (4 + 4 / (1 << L))))
+        del x, out
+if "fec" in what:
+    F = 2048
+    frames = torch.randint(0, 256, (F, 128, 512), generator=g, device=dev, dtype=torch.uint8)
+    frames[:, :, 2] = torch.arange(128, device=dev, dtype=torch.uint8)
+    ms = timed(K_FEC_ENCODE, lambda: sd.fec_encode_frames(ctx, frames, 32))
+    print("fec_encode 128+32  %8.3f ms / %d frames  %8.2f Mframes/s  %7.1f Gsamples/s-equivalent(decim16)" % (ms, F, F / ms / 1e3, F * 258064 / ms / 1e6))
+    rec = sd.fec_encode_frames(ctx, frames, 32)
+    allb = torch.cat([frames, rec], dim=1)
+    keep = [i for i in range(160) if i not in set(range(1, 121, 5))][:128]
+    rx = allb[:, keep].contiguous()
+    idx = rx[:, :, 2].cpu().numpy()
+    ms = timed(K_FEC_DECODE, lambda: sd.fec_decode_frames(ctx, rx, idx))
+    print("fec_decode 24 erasures (one pattern)  %8.3f ms / %d frames  %8.2f Mframes/s" % (ms, F, F / ms / 1e3))
