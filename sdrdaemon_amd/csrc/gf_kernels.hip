@@ -80,12 +80,14 @@ __global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArgs a)
     // this half-wave's frame (both frames of a group share one coefficient matrix)
     int fr = a.frame_list ? a.frame_list[group * GF_FRAMES_PER_GROUP + h] : group * GF_FRAMES_PER_GROUP + h;
     if (fr >= a.nframes) fr = -1;
-    const int cm = a.coef_per_frame ? group : 0;
+    // coefficient matrix of this group: shared (0), one per group, or an indirect slot of a pattern cache
+    const int cm = a.group_cm ? a.group_cm[group] : (a.coef_per_frame ? group : 0);
+    const size_t mstride = a.matrix_rows ? (size_t)a.matrix_rows : (size_t)a.rows; // rows between consecutive matrices
     const int cols = a.cols;
 
     for (int i = tid; i < 256 * 8; i += GF_NT) tab[i] = reinterpret_cast<const unsigned *>(a.tab)[i];
     {
-        const uint8_t *cg = a.coef + ((size_t)cm * a.rows + row0) * cols;
+        const uint8_t *cg = a.coef + ((size_t)cm * mstride + row0) * cols;
         const int nrows = (a.rows - row0) < ROWS_PER_WG ? (a.rows - row0) : ROWS_PER_WG;
         for (int i = tid; i < ROWS_PER_WG * cols; i += GF_NT) {
             int r = i / cols;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArgs a)
     }
 
     if (fr < 0) return;
-    const int16_t *rdst = a.row_dst ? a.row_dst + (size_t)cm * a.rows : nullptr;
+    const int16_t *rdst = a.row_dst ? a.row_dst + (size_t)cm * mstride : nullptr;
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int r = row0 + r0 + rb;

@@ -49,6 +49,33 @@ void DevBuf::release()
     cap = 0;
 }
 
+int PinnedBuf::reserve(size_t n)
+{
+    if (pending) { (void)hipEventSynchronize(ev); pending = false; }
+    if (n <= cap) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 2 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return fail(SDRHIP_ENOMEM, "hipHostMalloc(%zu) failed", want); }
+    cap = want;
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail(SDRHIP_EDEVICE, "hipEventCreate");
+    return 0;
+}
+
+void PinnedBuf::mark(hipStream_t s)
+{
+    if (ev && hipEventRecord(ev, s) == hipSuccess) pending = true;
+}
+
+void PinnedBuf::release()
+{
+    if (pending) (void)hipEventSynchronize(ev);
+    if (p) (void)hipHostFree(p);
+    if (ev) (void)hipEventDestroy(ev);
+    p = nullptr; cap = 0; ev = nullptr; pending = false;
+}
+
 } // namespace sdrhip
 
 extern "C" const char *sdrhip_last_error(void) { return g_err.c_str(); }
@@ -93,6 +120,9 @@ extern "C" void sdrhip_ctx_destroy(sdrhip_ctx *c)
     c->in.release(); c->out.release(); c->aux.release(); c->aux2.release(); c->aux3.release();
     if (c->gf_tab) (void)hipFree(c->gf_tab);
     if (c->enc_matrix) (void)hipFree(c->enc_matrix);
+    if (c->dec_coef) (void)hipFree(c->dec_coef);
+    if (c->dec_dst) (void)hipFree(c->dec_dst);
+    c->pin.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;

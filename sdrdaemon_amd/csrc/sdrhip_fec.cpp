@@ -41,112 +41,143 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
 {
     if (nframes == 0) return SDRHIP_OK;
     const int K = SDRHIP_NB_ORIGINAL;
-    // ---- host planning: scatter map for received originals + one decode matrix per distinct
-    // erasure pattern (frames with the same 128 indices share it)
-    std::vector<int16_t> map(nframes * (size_t)K);
-    std::map<std::string, int> pattern_of;
-    std::vector<std::vector<int32_t>> members;     // frames per pattern
-    std::vector<std::vector<uint8_t>> coefs;       // n_rec x K per pattern
-    std::vector<std::vector<int16_t>> dsts;        // n_rec destination block (-1 skip)
+    constexpr int SLOTS = sdrhip_ctx::DEC_SLOTS;
+    int rc;
+    if (!c->dec_coef) {
+        if (hipMalloc(reinterpret_cast<void **>(&c->dec_coef), (size_t)SLOTS * K * K) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&c->dec_dst), (size_t)2 * SLOTS * K * sizeof(int16_t)) != hipSuccess)
+            return fail(SDRHIP_ENOMEM, "hipMalloc decode-plan cache");
+    }
+    // ---- host planning.  Per frame: scatter maps for the received originals; frames that used
+    // recovery blocks (SDRdaemonFECBuffer.cpp:174) get the matrix slot of their erasure pattern, derived
+    // once per distinct pattern (restating CM256Decoder::Initialize/Decode) and cached on the device.
+    // staging layout: pmap[nframes*K] i16 | zmap[nframes*K] i16 | flist[2*nframes] i32 | gcm[nframes] i32 | new slots
+    const size_t nmap = nframes * (size_t)K;
+    const size_t o_pmap = 0, o_zmap = o_pmap + nmap * 2, o_flist = (o_zmap + nmap * 2 + 15) & ~(size_t)15;
+    const size_t o_gcm = o_flist + nframes * GF_FRAMES_PER_GROUP * 4, o_new = (o_gcm + nframes * 4 + 15) & ~(size_t)15;
+    const size_t slot_bytes = (size_t)K * K + 2 * K * sizeof(int16_t);
+    if ((rc = c->pin.reserve(o_new + (size_t)SLOTS * slot_bytes))) return rc;
+    if ((rc = c->aux.reserve(o_new))) return rc;
+    uint8_t *hp = c->pin.as<uint8_t>();
+    int16_t *pmap = reinterpret_cast<int16_t *>(hp + o_pmap), *zmap = reinterpret_cast<int16_t *>(hp + o_zmap);
+    int32_t *flist = reinterpret_cast<int32_t *>(hp + o_flist), *gcm = reinterpret_cast<int32_t *>(hp + o_gcm);
+
+    std::vector<std::vector<int32_t>> members; // frames per slot used by this call
+    std::vector<int> used_slots;
+    std::map<int, int> member_of;              // slot -> index in members
+    std::vector<int> new_slots;
     std::vector<uint8_t> coef((size_t)K * K), rec_pos(K), erased(256);
     int max_rows = 0;
+    bool any_b0 = false;
     for (size_t f = 0; f < nframes; ++f) {
         const uint8_t *idx = indices + f * K;
         int n_recovery = 0;
         for (int p = 0; p < K; ++p) {
-            map[f * K + p] = idx[p] < K ? (int16_t)idx[p] : (int16_t)-1;
-            if (idx[p] >= K) ++n_recovery;
+            const int b = idx[p];
+            pmap[f * K + p] = (b >= 1 && b < K) ? (int16_t)(b - 1) : (int16_t)-1; // payload slot of block b
+            zmap[f * K + p] = b == 0 ? (int16_t)0 : (int16_t)-1;
+            if (b >= K) ++n_recovery;
         }
-        if (n_recovery == 0) continue; // SDRdaemonFECBuffer.cpp:174: decode only if recovery blocks were used
+        if (n_recovery == 0) continue;
         std::string key(reinterpret_cast<const char *>(idx), K);
-        auto it = pattern_of.find(key);
-        if (it == pattern_of.end()) {
+        auto it = c->dec_slot_of.find(key);
+        if (it == c->dec_slot_of.end()) {
+            // a slot for the new pattern: a free one, a fresh one, or evict the patterns this call does not use
+            int slot = -1;
+            if (!c->dec_free.empty()) {
+                slot = c->dec_free.back();
+                c->dec_free.pop_back();
+            } else if ((int)c->dec_nrec.size() < SLOTS) {
+                slot = (int)c->dec_nrec.size();
+                c->dec_nrec.push_back(0);
+                c->dec_b0.push_back(0);
+            } else {
+                std::vector<char> busy(SLOTS, 0);
+                for (size_t u = 0; u < used_slots.size(); ++u) busy[used_slots[u]] = 1;
+                for (size_t u = 0; u < new_slots.size(); ++u) busy[new_slots[u]] = 1;
+                for (auto jt = c->dec_slot_of.begin(); jt != c->dec_slot_of.end();) {
+                    if (jt->second >= 0 && !busy[jt->second]) { c->dec_free.push_back(jt->second); jt = c->dec_slot_of.erase(jt); }
+                    else ++jt;
+                }
+                if (c->dec_free.empty())
+                    return fail(SDRHIP_EINVAL, "fec_decode: more than %d distinct erasure patterns in one batch; split the batch", SLOTS);
+                slot = c->dec_free.back();
+                c->dec_free.pop_back();
+            }
             int n_rec = 0;
             // the reference passes the number of RECEIVED recovery blocks as RecoveryCount (:176)
-            int rc = cm256_decode_plan(K, n_recovery, idx, &n_rec, rec_pos.data(), erased.data(), coef.data());
-            if (rc) {
-                // "CM256 decode error" (:199): the frame keeps what was received
-                pattern_of[key] = -1;
+            if (cm256_decode_plan(K, n_recovery, idx, &n_rec, rec_pos.data(), erased.data(), coef.data())) {
+                c->dec_free.push_back(slot);
+                c->dec_slot_of[key] = -1; // "CM256 decode error" (:199): the frame keeps what was received
                 continue;
             }
-            std::vector<int16_t> d(n_rec);
-            for (int i = 0; i < n_rec; ++i) d[i] = (int16_t)erased[i];
-            it = pattern_of.insert(std::make_pair(key, (int)coefs.size())).first;
-            coefs.push_back(std::vector<uint8_t>(coef.begin(), coef.begin() + (size_t)n_rec * K));
-            dsts.push_back(d);
-            members.push_back(std::vector<int32_t>());
-            if (n_rec > max_rows) max_rows = n_rec;
+            c->dec_nrec[slot] = n_rec;
+            c->dec_b0[slot] = 0;
+            it = c->dec_slot_of.insert(std::make_pair(key, slot)).first;
+            uint8_t *sp = hp + o_new + new_slots.size() * slot_bytes;
+            memset(sp, 0, slot_bytes);
+            memcpy(sp, coef.data(), (size_t)n_rec * K);
+            int16_t *dp = reinterpret_cast<int16_t *>(sp + (size_t)K * K), *dz = dp + K;
+            for (int i = 0; i < K; ++i) { dp[i] = -1; dz[i] = -1; }
+            for (int i = 0; i < n_rec; ++i) {
+                if (erased[i] >= 1 && erased[i] < K) dp[i] = (int16_t)(erased[i] - 1);
+                if (erased[i] == 0) { dz[i] = 0; c->dec_b0[slot] = 1; }
+            }
+            new_slots.push_back(slot);
         }
-        if (it->second >= 0) members[it->second].push_back((int32_t)f);
+        const int slot = it->second;
+        if (slot < 0) continue;
+        auto mo = member_of.find(slot);
+        if (mo == member_of.end()) {
+            mo = member_of.insert(std::make_pair(slot, (int)members.size())).first;
+            members.push_back(std::vector<int32_t>());
+            used_slots.push_back(slot);
+            if (c->dec_nrec[slot] > max_rows) max_rows = c->dec_nrec[slot];
+            any_b0 |= c->dec_b0[slot] != 0;
+        }
+        members[mo->second].push_back((int32_t)f);
     }
+    int ngroups = 0;
+    for (size_t u = 0; u < members.size(); ++u)
+        for (size_t i = 0; i < members[u].size(); i += GF_FRAMES_PER_GROUP) {
+            for (size_t v = 0; v < (size_t)GF_FRAMES_PER_GROUP; ++v) flist[ngroups * GF_FRAMES_PER_GROUP + v] = i + v < members[u].size() ? members[u][i + v] : -1;
+            gcm[ngroups++] = used_slots[u];
+        }
+    // ---- uploads (pinned, asynchronous): maps + lists in one copy, new matrices into their slots
+    uint8_t *dv = c->aux.as<uint8_t>();
+    HIP_TRY(hipMemcpyAsync(dv, hp, o_new, hipMemcpyHostToDevice, c->stream));
+    for (size_t i = 0; i < new_slots.size(); ++i) {
+        const uint8_t *sp = hp + o_new + i * slot_bytes;
+        const int slot = new_slots[i];
+        HIP_TRY(hipMemcpyAsync(c->dec_coef + (size_t)slot * K * K, sp, (size_t)K * K, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->dec_dst + (size_t)slot * K, sp + (size_t)K * K, K * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->dec_dst + (size_t)(SLOTS + slot) * K, sp + (size_t)K * K + K * sizeof(int16_t), K * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    }
+    c->pin.mark(c->stream);
+
     // ---- payload = zeros (initDecodeSlot memset, :109) + received originals in place
-    // destination frame layout: block b (0..127) at dst_base + b * 508 where block 0 goes to
-    // block0_out (or nowhere) and blocks 1.. to payload_out: use two scatters via a map with -1
-    int rc;
-    const size_t map_bytes = map.size() * sizeof(int16_t);
-    if ((rc = c->aux.reserve(map_bytes))) return rc;
     HIP_TRY(hipMemsetAsync(payload_out, 0, nframes * payload_frame_bytes, c->stream));
-    // payload scatter: block index i >= 1 -> slot i - 1
-    std::vector<int16_t> pmap(map.size()), zmap(map.size());
-    for (size_t i = 0; i < map.size(); ++i) {
-        pmap[i] = map[i] >= 1 ? (int16_t)(map[i] - 1) : (int16_t)-1;
-        zmap[i] = map[i] == 0 ? (int16_t)0 : (int16_t)-1;
-    }
-    HIP_TRY(hipMemcpyAsync(c->aux.p, pmap.data(), map_bytes, hipMemcpyHostToDevice, c->stream));
     hipError_t e = launch_block_scatter(rx, rx_frame_bytes, SDRHIP_UDPSIZE, 4, payload_out, payload_frame_bytes, SDRHIP_BLOCK_BYTES, 0,
-                                        c->aux.as<int16_t>(), K, (int)nframes, c->stream);
+                                        reinterpret_cast<const int16_t *>(dv + o_pmap), K, (int)nframes, c->stream);
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "scatter launch: %s", hipGetErrorString(e));
-    HIP_TRY(hipStreamSynchronize(c->stream)); // pmap is a host temporary
     if (block0_out) {
         HIP_TRY(hipMemsetAsync(block0_out, 0, nframes * (size_t)SDRHIP_BLOCK_BYTES, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->aux.p, zmap.data(), map_bytes, hipMemcpyHostToDevice, c->stream));
         e = launch_block_scatter(rx, rx_frame_bytes, SDRHIP_UDPSIZE, 4, block0_out, SDRHIP_BLOCK_BYTES, SDRHIP_BLOCK_BYTES, 0,
-                                 c->aux.as<int16_t>(), K, (int)nframes, c->stream);
+                                 reinterpret_cast<const int16_t *>(dv + o_zmap), K, (int)nframes, c->stream);
         if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "scatter launch: %s", hipGetErrorString(e));
-        HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    if (coefs.empty()) return SDRHIP_OK;
+    if (ngroups == 0) return SDRHIP_OK;
 
-    // ---- groups of GF_FRAMES_PER_GROUP frames sharing a pattern
-    std::vector<int32_t> frame_list;
-    std::vector<int> group_pattern;
-    for (size_t pt = 0; pt < members.size(); ++pt)
-        for (size_t i = 0; i < members[pt].size(); i += GF_FRAMES_PER_GROUP) {
-            for (size_t u = 0; u < (size_t)GF_FRAMES_PER_GROUP; ++u) frame_list.push_back(i + u < members[pt].size() ? members[pt][i + u] : -1);
-            group_pattern.push_back((int)pt);
-        }
-    const int ngroups = (int)group_pattern.size();
-    const int rows = max_rows;
-    std::vector<uint8_t> gcoef((size_t)ngroups * rows * K, 0);
-    std::vector<int16_t> gdst_payload((size_t)ngroups * rows, -1), gdst_b0((size_t)ngroups * rows, -1);
-    bool any_b0 = false;
-    for (int g = 0; g < ngroups; ++g) {
-        const std::vector<uint8_t> &cf = coefs[group_pattern[g]];
-        const std::vector<int16_t> &d = dsts[group_pattern[g]];
-        memcpy(&gcoef[(size_t)g * rows * K], cf.data(), cf.size());
-        for (size_t i = 0; i < d.size(); ++i) {
-            if (d[i] >= 1 && d[i] < K) gdst_payload[(size_t)g * rows + i] = (int16_t)(d[i] - 1);
-            if (d[i] == 0) { gdst_b0[(size_t)g * rows + i] = 0; any_b0 = true; }
-        }
-    }
-    const size_t o_coef = 0, o_list = (gcoef.size() + 15) & ~(size_t)15, o_dst = o_list + ((frame_list.size() * 4 + 15) & ~(size_t)15);
-    const size_t o_dst0 = o_dst + ((gdst_payload.size() * 2 + 15) & ~(size_t)15);
-    const size_t total = o_dst0 + gdst_b0.size() * 2 + 16;
-    if ((rc = c->aux2.reserve(total))) return rc;
-    uint8_t *base = c->aux2.as<uint8_t>();
-    HIP_TRY(hipMemcpyAsync(base + o_coef, gcoef.data(), gcoef.size(), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(base + o_list, frame_list.data(), frame_list.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(base + o_dst, gdst_payload.data(), gdst_payload.size() * 2, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(base + o_dst0, gdst_b0.data(), gdst_b0.size() * 2, hipMemcpyHostToDevice, c->stream));
     GfArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = rx; a.out = payload_out; a.coef = base + o_coef; a.tab = c->gf_tab;
+    a.in = rx; a.out = payload_out; a.coef = c->dec_coef; a.tab = c->gf_tab;
     a.in_frame_bytes = rx_frame_bytes; a.out_frame_bytes = payload_frame_bytes;
     a.in_pitch = SDRHIP_UDPSIZE; a.in_off = 4; a.out_pitch = SDRHIP_BLOCK_BYTES; a.out_off = 0;
-    a.rows = rows; a.cols = K; a.coef_per_frame = 1;
-    a.row_dst = reinterpret_cast<const int16_t *>(base + o_dst);
+    a.rows = max_rows; a.cols = K; a.matrix_rows = K;
+    a.row_dst = c->dec_dst;
     a.nframes = (int)nframes;
-    a.frame_list = reinterpret_cast<const int32_t *>(base + o_list);
+    a.frame_list = reinterpret_cast<const int32_t *>(dv + o_flist);
+    a.group_cm = reinterpret_cast<const int32_t *>(dv + o_gcm);
     a.ngroups = ngroups;
     {
         KTimer kt(c, SDRHIP_K_FEC_DECODE);
@@ -155,11 +186,10 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec decode launch: %s", hipGetErrorString(e));
     if (block0_out && any_b0) {
         a.out = block0_out; a.out_frame_bytes = SDRHIP_BLOCK_BYTES;
-        a.row_dst = reinterpret_cast<const int16_t *>(base + o_dst0);
+        a.row_dst = c->dec_dst + (size_t)SLOTS * K;
         e = launch_gf_apply(a, c->stream);
         if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec decode launch: %s", hipGetErrorString(e));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream)); // host temporaries were the copy sources
     return SDRHIP_OK;
 }
 

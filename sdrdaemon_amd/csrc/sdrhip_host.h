@@ -4,6 +4,7 @@
 #include "sdrhip_internal.h"
 
 #include <cstdint>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -23,6 +24,18 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     int reserve(size_t n);
+    void release();
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// growable pinned host staging buffer; reuse waits for the previous upload that read from it
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int reserve(size_t n);                 // also waits for the pending upload
+    void mark(hipStream_t s);              // call after enqueueing the copies that read from p
     void release();
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
@@ -53,6 +66,15 @@ struct sdrhip_ctx {
     uint8_t *gf_tab = nullptr;               // 256 x 32 B multiplier tables (device)
     uint8_t *enc_matrix = nullptr;           // 128 x 128 encode matrix, rows 128..255 (device)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // decode-plan cache: erasure pattern (the 128 received block indices) -> matrix slot on the device
+    static constexpr int DEC_SLOTS = 64;
+    std::map<std::string, int> dec_slot_of;      // slot, or -1 for an undecodable pattern
+    std::vector<int> dec_nrec;                   // rows of each slot
+    std::vector<int> dec_free;                   // recycled slots
+    std::vector<char> dec_b0;                    // slot recovers block 0 (the meta block)
+    uint8_t *dec_coef = nullptr;                 // [DEC_SLOTS][128][128]
+    int16_t *dec_dst = nullptr;                  // [2][DEC_SLOTS][128]: payload destination, block-0 destination
+    sdrhip::PinnedBuf pin;                       // per-call upload staging (maps, frame lists)
     // per-kernel-class timing with hipEvents on `stream` (sdrhip_ctx_kernel_timing)
     bool ktime_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> kev[4];

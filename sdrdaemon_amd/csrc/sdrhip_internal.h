@@ -88,6 +88,10 @@ struct GfArgs {
     // group when coef_per_frame, else 0): frame_list[group * GF_FRAMES_PER_GROUP + slot] (or -1), NULL = identity
     const int32_t *frame_list;
     int ngroups;
+    // optional indirection: matrix slot of each group (pattern cache); matrices / row_dst tables are then
+    // matrix_rows rows apart (0 = tightly packed, `rows` apart)
+    const int32_t *group_cm;
+    int matrix_rows;
 };
 hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream);
 hipError_t launch_block_scatter(const uint8_t *src, size_t src_frame_bytes, int src_pitch, int src_off, uint8_t *dst,

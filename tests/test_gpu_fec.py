@@ -133,3 +133,26 @@ def test_incomplete_frame_keeps_zeros(ctx, oracle):
     frames = oracle.framer(nb_fec_blocks=0).write(x)
     payload = sd.fec_decode_frames(ctx, frames)
     assert np.array_equal(payload[0].view(np.int16).reshape(-1, 2), x)
+
+
+def test_decode_plan_cache_many_patterns(ctx, oracle):
+    """Repeated batches with fresh random erasure patterns: the device-side plan cache (64 slots)
+    fills, is reused and is recycled; every frame must still decode exactly."""
+    import sdrdaemon_amd as sd
+
+    R = 32
+    rs = np.random.RandomState(123)
+    x = signals.noise(30 * 16129, 55)
+    frames = oracle.framer(nb_fec_blocks=R).write(x)
+    rec = np.stack([oracle.frame_encode(f, R) for f in frames])
+    fixed = sorted(rs.choice(160, 20, replace=False).tolist())
+    for call in range(5):
+        rx = np.zeros((30, 128, 512), np.uint8)
+        for f in range(30):
+            lost = set(fixed) if f % 2 == 0 else set(rs.choice(160, int(rs.randint(1, 33)), replace=False).tolist())
+            allb = np.concatenate([frames[f], rec[f]])
+            rx[f] = allb[[i for i in range(160) if i not in lost][:128]]
+        payload, b0 = sd.fec_decode_frames(ctx, rx, want_block0=True)
+        for f in range(30):
+            assert np.array_equal(payload[f].view(np.int16).reshape(-1, 2), x[f * 16129:(f + 1) * 16129]), (call, f)
+            assert np.array_equal(b0[f], frames[f, 0, 4:]), (call, f)

@@ -65,3 +65,27 @@ if "fec" in what:
     idx = rx[:, :, 2].cpu().numpy()
     ms = timed(K_FEC_DECODE, lambda: sd.fec_decode_frames(ctx, rx, idx))
     print("fec_decode 24 erasures (one pattern)  %8.3f ms / %d frames  %8.2f Mframes/s" % (ms, F, F / ms / 1e3))
+if "tx" in what:
+    import time
+
+    F, R = 128, 32
+    Stx = 8
+    frames = torch.randint(0, 256, (Stx * F, 128, 512), generator=g, device=dev, dtype=torch.uint8)
+    frames[:, :, 2] = torch.arange(128, device=dev, dtype=torch.uint8)
+    rec = sd.fec_encode_frames(ctx, frames, R)
+    allb = torch.cat([frames, rec], dim=1)
+    keep = [i for i in range(160) if i not in set(range(1, 121, 5))][:128]
+    rx = allb[:, keep].contiguous().reshape(Stx, F, 128, 512)
+    idx = rx[:, :, :, 2].cpu().numpy()
+    tx = sd.TxPipe(ctx, Stx, 4)
+    tx.process(rx, idx)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        y = tx.process(rx, idx)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    nout = Stx * F * 16129 * 16
+    print("tx pipe (decode 24 erasures + interpolate16) %8.3f ms / step  %8.1f Gsamples/s out  %7.1f GB/s (4.254 B/out)" %
+          (dt * 1e3, nout / dt / 1e9, nout / dt / 1e9 * 4.254))
