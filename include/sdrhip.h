@@ -181,6 +181,12 @@ int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in, size_t i
                       uint32_t tv_usec, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames,
                       int mem);
 size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in);
+/* Zero-copy alternative for device-side consumers (what transmitUDP does when it sends straight
+ * from m_txBlocks, UDPSinkFEC.cpp:259-282): call sdrhip_rx_process with frames_out = NULL and
+ * mem = SDRHIP_MEM_DEVICE, then read the n_frames finished frames of stream s at
+ * base + s * stream_stride_bytes (device memory, frame after frame).  The view stays valid until
+ * the next sdrhip_rx_process / sdrhip_rx_destroy on this handle. */
+int sdrhip_rx_frames_view(const sdrhip_rx *rx, const uint8_t **base, size_t *stream_stride_bytes, size_t *n_frames);
 
 /* ------------------------------------------------------------ fused Tx pipe -- */
 /* Bank of Tx chains: SDRdaemonFECBuffer decode (SDRdaemonFECBuffer.cpp:143-213) ->

@@ -130,6 +130,9 @@ struct sdrhip_rx {
     bool frame_open;          // slot 0 has its meta block (a frame was started)
     uint16_t frame_count;     // m_frameCount of slot 0
     DevBuf meta;              // 24-byte meta record (device)
+    DevBuf pending;           // [nstreams][128 + nb_fec][512]: the partial frame between calls
+    PinnedBuf meta_pin;
+    size_t view_frames = 0;   // finished frames of the last call, readable in `work`
     DevBuf flist;             // frame list of the encode launch (device)
     std::vector<int32_t> flist_host;
     size_t flist_done = 0, flist_cap = 0;
@@ -162,7 +165,18 @@ extern "C" void sdrhip_rx_destroy(sdrhip_rx *rx)
     rx->work.release();
     rx->meta.release();
     rx->flist.release();
+    rx->pending.release();
+    rx->meta_pin.release();
     delete rx;
+}
+
+extern "C" int sdrhip_rx_frames_view(const sdrhip_rx *rx, const uint8_t **base, size_t *stream_stride_bytes, size_t *n_frames)
+{
+    if (!rx || !base || !stream_stride_bytes || !n_frames) return fail(SDRHIP_EINVAL, "rx_frames_view: NULL argument");
+    *base = rx->work.as<uint8_t>();
+    *stream_stride_bytes = rx->cap_frames * (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
+    *n_frames = rx->view_frames;
+    return SDRHIP_OK;
 }
 
 extern "C" size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in)
@@ -188,8 +202,8 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     const size_t done = (size_t)(total / SDRHIP_SAMPLES_PER_FRAME);
     const uint64_t rest = total - (uint64_t)done * SDRHIP_SAMPLES_PER_FRAME;
     if (S == 1) in_stride = n_in;
-    if (done && !frames_out) return fail(SDRHIP_EINVAL, "rx_process: NULL frames_out");
-    if (S > 1 && done && frame_stride_bytes < done * frame_bytes) return fail(SDRHIP_EINVAL, "rx_process: frame stride too small");
+    if (done && !frames_out && mem != SDRHIP_MEM_DEVICE) return fail(SDRHIP_EINVAL, "rx_process: NULL frames_out");
+    if (frames_out && S > 1 && done && frame_stride_bytes < done * frame_bytes) return fail(SDRHIP_EINVAL, "rx_process: frame stride too small");
 
     const int16_t *din = iq_in;
     size_t dstride = in_stride;
@@ -205,21 +219,22 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         return fail(SDRHIP_EINVAL, "mem must be SDRHIP_MEM_HOST or SDRHIP_MEM_DEVICE");
     }
 
-    // ---- work area: slot 0 = the frame being filled, grows to done + 1 slots
+    // ---- work area [stream][slot][128 + R][512]: slot 0 = the frame being filled (it waits in
+    // `pending` between calls, so that the finished frames of a call stay readable in place until the
+    // next call: sdrhip_rx_frames_view), grows to done + 1 slots
     const size_t need = done + 1;
     if (need > rx->cap_frames) {
-        DevBuf nw;
+        HIP_TRY(hipStreamSynchronize(c->stream)); // earlier launches may still use the old area
         const size_t ncap = need + need / 2;
-        if ((rc = nw.reserve((size_t)S * ncap * frame_bytes))) return rc;
-        if (rx->cap_frames) // keep the partial frame of every stream
-            HIP_TRY(hipMemcpy2DAsync(nw.p, ncap * frame_bytes, rx->work.p, rx->cap_frames * frame_bytes, frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
         rx->work.release();
-        rx->work = nw;
+        if ((rc = rx->work.reserve((size_t)S * ncap * frame_bytes))) { rx->cap_frames = 0; return rc; }
         rx->cap_frames = ncap;
     }
+    if ((rc = rx->pending.reserve((size_t)S * frame_bytes))) return rc;
     uint8_t *work = rx->work.as<uint8_t>();
     const size_t stream_bytes = rx->cap_frames * frame_bytes;
+    if (rx->frame_open)
+        HIP_TRY(hipMemcpy2DAsync(work, stream_bytes, rx->pending.p, frame_bytes, frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
 
     // ---- decimate straight into the frame layout
     unsigned ss = rx->cfg.sample_bits;
@@ -247,8 +262,10 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         }
         crc ^= 0xFFFFFFFFu;
         memcpy(m + 20, &crc, 4);
-        HIP_TRY(hipMemcpyAsync(rx->meta.p, m, 24, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream)); // m is a stack temporary
+        if ((rc = rx->meta_pin.reserve(32))) return rc; // waits for the previous call's upload, long done
+        memcpy(rx->meta_pin.p, m, 24);
+        HIP_TRY(hipMemcpyAsync(rx->meta.p, rx->meta_pin.p, 24, hipMemcpyHostToDevice, c->stream));
+        rx->meta_pin.mark(c->stream);
         hipError_t e = launch_frame_meta(work, stream_bytes, FB, S, first_new, started, (unsigned)rx->frame_count + first_new,
                                          rx->meta.as<uint8_t>(), c->stream);
         if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "frame meta launch: %s", hipGetErrorString(e));
@@ -271,13 +288,13 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
                                     frame_bytes, rx->flist.as<int32_t>(), (int)(rx->flist_host.size() / GF_FRAMES_PER_GROUP))))
             return rc;
     }
-    if (done) {
+    if (done && frames_out)
         HIP_TRY(hipMemcpy2DAsync(frames_out, S > 1 ? frame_stride_bytes : done * frame_bytes, work, stream_bytes, done * frame_bytes, S,
                                  mem == SDRHIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
-        // the frame still being filled moves to slot 0
-        if (rest > 0)
-            HIP_TRY(hipMemcpy2DAsync(work, stream_bytes, work + done * frame_bytes, stream_bytes, frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
-    }
+    // the frame still being filled waits in `pending`
+    if (rest > 0)
+        HIP_TRY(hipMemcpy2DAsync(rx->pending.p, frame_bytes, work + done * frame_bytes, stream_bytes, frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
+    rx->view_frames = done;
     rx->pending_samples = rest;
     rx->frame_open = rest > 0;
     rx->frame_count = (uint16_t)(rx->frame_count + done);

@@ -346,6 +346,21 @@ def fec_decode_frames(ctx, rx, indices=None, want_block0=False):
     return (payload, b0) if want_block0 else payload
 
 
+class _DeviceView:
+    """A strided uint8 view of library-owned device memory (__cuda_array_interface__ v2)."""
+
+    def __init__(self, ptr, shape, strides, device):
+        self.shape, self.device = tuple(shape), device
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "strides": tuple(strides), "typestr": "|u1",
+                                         "data": (ptr, False), "version": 2}
+
+    def torch(self):
+        """materialise as a torch tensor sharing the memory"""
+        if self.shape[1] == 0:
+            return torch.empty(self.shape, dtype=torch.uint8, device=self.device)
+        return torch.as_tensor(self, device=self.device)
+
+
 class RxPipe:
     """Downsampler -> UDPSinkFEC framing -> CM256 encode for a bank of streams (sdrhip_rx)."""
 
@@ -376,6 +391,21 @@ class RxPipe:
                                              C.byref(nf), MEM_DEVICE if is_t else MEM_HOST))
         out = out[:, :nf.value]
         return out[0] if squeeze else out
+
+    def process_view(self, iq, tv_sec=0, tv_usec=0):
+        """Zero-copy variant for CUDA tensors: the finished frames stay in the library's frame area.
+        -> uint8 CUDA tensor view (S, n_frames, 128 + nb_fec, 512), valid until the next process call."""
+        x, is_t, squeeze = _bank_view(iq, self.nstreams)
+        if not is_t:
+            raise TypeError("process_view needs a CUDA tensor")
+        S, n = x.shape[0], x.shape[1]
+        nf = C.c_size_t(0)
+        check(self.ctx.lib.sdrhip_rx_process(self.h, _ptr(x), n, _stride_samples(x), tv_sec, tv_usec, C.c_void_p(0), 0,
+                                             C.byref(nf), MEM_DEVICE))
+        base, stride, cnt = C.c_void_p(0), C.c_size_t(0), C.c_size_t(0)
+        check(self.ctx.lib.sdrhip_rx_frames_view(self.h, C.byref(base), C.byref(stride), C.byref(cnt)))
+        fb = (NB_ORIGINAL + self.nb_fec) * UDPSIZE
+        return _DeviceView(base.value, (S, cnt.value, NB_ORIGINAL + self.nb_fec, UDPSIZE), (stride.value, fb, UDPSIZE, 1), x.device)
 
     def close(self):
         if self.h:

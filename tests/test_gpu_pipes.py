@@ -172,3 +172,27 @@ def test_roundtrip_rx_to_tx_full_size_property(ctx):
     ctx.synchronize()
     got = payload.reshape(S, F * 16129 * 4).view(torch.int16).reshape(S, F * 16129, 2)
     assert torch.equal(got, y[:, :F * 16129])
+
+
+def test_rx_zero_copy_view_equals_copy(ctx, oracle):
+    """frames_out = NULL + sdrhip_rx_frames_view: same frames as the copying call, across calls with
+    frames straddling the call boundary."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    S = 3
+    x = np.stack([signals.noise(5 * 16129 * 16 + 4096, 70 + s) for s in range(S)])
+    xd = torch.from_numpy(x).cuda()
+    a, b = sd.RxPipe(ctx, S, log2decim=4, nb_fec=32), sd.RxPipe(ctx, S, log2decim=4, nb_fec=32)
+    cuts = [0, 300000, 300016, 900000, x.shape[1]]
+    total = 0
+    for i in range(4):
+        seg = xd[:, cuts[i]:cuts[i + 1]].contiguous()
+        fa = a.process(seg, i, i)
+        fb = b.process_view(seg, i, i).torch().clone()
+        ctx.synchronize()
+        assert fa.shape == fb.shape
+        assert torch.equal(fa, fb), i
+        total += fa.shape[1]
+    assert total == 5
