@@ -89,3 +89,27 @@ if "tx" in what:
     nout = Stx * F * 16129 * 16
     print("tx pipe (decode 24 erasures + interpolate16) %8.3f ms / step  %8.1f Gsamples/s out  %7.1f GB/s (4.254 B/out)" %
           (dt * 1e3, nout / dt / 1e9, nout / dt / 1e9 * 4.254))
+if "host" in what:
+    import time
+
+    import numpy as np
+
+    Sh, n = 8, 1 << 23
+    xh = np.random.RandomState(1).randint(-32768, 32768, size=(Sh, n, 2)).astype(np.int16)
+    rxp = sd.RxPipe(ctx, Sh, log2decim=4, nb_fec=32)
+    rxp.process(xh)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        fr = rxp.process(xh)
+    dt = (time.perf_counter() - t0) / reps
+    print("rx pipe, HOST buffers (pageable numpy in, frames out): %8.2f ms / step  %7.2f Gsamples/s  (%5.1f GB/s over PCIe)" %
+          (dt * 1e3, Sh * n / dt / 1e9, (xh.nbytes + fr.nbytes) / dt / 1e9))
+    d1 = sd.Decimators(ctx, 1, 0)
+    blk = xh[0, :65536]
+    d1.decimate(4, 2, 16, blk)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        d1.decimate(4, 2, 16, blk)
+    dt = (time.perf_counter() - t0) / 200
+    print("single TestSource block (65536 samples, host pointers, one stream): %7.1f us / call  %6.3f Gsamples/s" % (dt * 1e6, 65536 / dt / 1e9))
