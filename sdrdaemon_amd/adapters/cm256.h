@@ -5,6 +5,8 @@
 #ifndef SDRHIP_CM256_ADAPTER_H
 #define SDRHIP_CM256_ADAPTER_H
 
+#include <string.h> // SDRdaemonFECBuffer.h relies on cm256.h for memcmp/memset
+
 #include "sdrhip_adapter_common.h"
 
 class CM256
