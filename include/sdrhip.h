@@ -63,6 +63,8 @@ int sdrhip_device_count(void);
  * (e.g. torch.cuda.current_stream().cuda_stream), or NULL for the device's null stream. */
 typedef struct sdrhip_ctx sdrhip_ctx;
 int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out);
+/* Handles created on a context keep it alive: destroying the context first only marks it, the last
+ * handle to be destroyed frees it. */
 void sdrhip_ctx_destroy(sdrhip_ctx *ctx);
 int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
 /* Average duration in milliseconds of the kernels launched between timing_begin and

@@ -112,9 +112,26 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
     return SDRHIP_OK;
 }
 
+namespace sdrhip {
+static void ctx_free(sdrhip_ctx *c);
+void ctx_retain(sdrhip_ctx *c) { ++c->refs; }
+void ctx_release(sdrhip_ctx *c)
+{
+    if (--c->refs == 0 && c->dying) ctx_free(c);
+}
+} // namespace sdrhip
+
+// Handles created on a context keep it alive: destroying the context first only marks it; the
+// last handle to go frees it (destruction order is then irrelevant, e.g. under a garbage collector).
 extern "C" void sdrhip_ctx_destroy(sdrhip_ctx *c)
 {
-    if (!c) return;
+    if (!c || c->dying) return;
+    c->dying = true;
+    if (c->refs == 0) ctx_free(c);
+}
+
+static void sdrhip::ctx_free(sdrhip_ctx *c)
+{
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->in.release(); c->out.release(); c->aux.release(); c->aux2.release(); c->aux3.release();
@@ -202,6 +219,7 @@ extern "C" int sdrhip_decimators_create(sdrhip_ctx *ctx, int nstreams, int hb_va
         delete d;
         return fail(SDRHIP_ENOMEM, "hipMalloc decimator state");
     }
+    ctx_retain(ctx);
     *out = d;
     return sdrhip_decimators_reset(d);
 }
@@ -213,6 +231,7 @@ extern "C" void sdrhip_decimators_destroy(sdrhip_decimators *d)
     (void)hipStreamSynchronize(d->ctx->stream);
     (void)hipFree(d->state[0]);
     (void)hipFree(d->state[1]);
+    ctx_release(d->ctx);
     delete d;
 }
 

@@ -42,6 +42,9 @@ struct PinnedBuf {
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+void ctx_retain(sdrhip_ctx *c);
+void ctx_release(sdrhip_ctx *c);
+
 // device-pointer cores (no argument validation, no staging)
 int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in, size_t n_in,
                     size_t in_stride, int16_t *out, size_t out_stride, size_t *n_out, int frame_mode, int frame_blocks,
@@ -62,6 +65,8 @@ int fec_decode_device(sdrhip_ctx *ctx, const uint8_t *rx, size_t rx_frame_bytes,
 struct sdrhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    int refs = 0;       // handles created on this context (they keep it alive)
+    bool dying = false; // sdrhip_ctx_destroy was called while handles were still alive
     sdrhip::DevBuf in, out, aux, aux2, aux3; // staging for SDRHIP_MEM_HOST calls and FEC work areas
     uint8_t *gf_tab = nullptr;               // 256 x 32 B multiplier tables (device)
     uint8_t *enc_matrix = nullptr;           // 128 x 128 encode matrix, rows 128..255 (device)

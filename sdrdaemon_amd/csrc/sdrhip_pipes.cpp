@@ -31,6 +31,7 @@ extern "C" int sdrhip_interpolators_create(sdrhip_ctx *ctx, int nstreams, sdrhip
         delete p;
         return fail(SDRHIP_ENOMEM, "hipMalloc interpolator state");
     }
+    ctx_retain(ctx);
     *out = p;
     return sdrhip_interpolators_reset(p);
 }
@@ -42,6 +43,7 @@ extern "C" void sdrhip_interpolators_destroy(sdrhip_interpolators *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     (void)hipFree(p->state[0]);
     (void)hipFree(p->state[1]);
+    ctx_release(p->ctx);
     delete p;
 }
 

@@ -138,7 +138,7 @@ class Decimators:
         Returns (out, new_sample_size)."""
         x, is_t, squeeze = _bank_view(iq, self.nstreams)
         S, n = x.shape[0], x.shape[1]
-        n_res = n >> log2decim
+        n_res = (n >> log2decim) if 0 <= log2decim <= 6 else 0  # out-of-range factors are rejected by the library
         if out is None:
             if is_t:  # per-stream rows padded to a multiple of 4 samples (16-byte aligned rows)
                 pad = (n_res + 3) & ~3
@@ -153,7 +153,6 @@ class Decimators:
         check(self.ctx.lib.sdrhip_decimate(self.h, log2decim, fcpos, C.byref(ss), _ptr(x), n, _stride_samples(x), _ptr(out),
                                            _stride_samples(out) if S > 1 else n_res, C.byref(n_out),
                                            MEM_DEVICE if is_t else MEM_HOST))
-        assert n_out.value == n_res
         return (out[0] if squeeze else out), ss.value
 
     def close(self):
@@ -227,7 +226,7 @@ class Interpolators:
         """Interpolators::interpolate<2^log2interp>_cen(in, out)."""
         x, is_t, squeeze = _bank_view(iq, self.nstreams)
         S, n = x.shape[0], x.shape[1]
-        n_res = n << log2interp
+        n_res = (n << log2interp) if 0 <= log2interp <= 6 else 0
         if out is None:
             if is_t:
                 pad = (n_res + 3) & ~3
