@@ -48,6 +48,19 @@ def make_input(device, n, seed, kind):
     return x.to(torch.int16)
 
 
+def pmc_traffic(samples_per_launch):
+    """HBM bytes per launch of the decimator kernel from the committed PMC passes (profiles/traffic.json,
+    collected with tools/prof.sh on this very command); None when the launch geometry differs."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)["decim_kernel<4,2,true>"]
+        if int(t["samples_per_launch"]) != int(samples_per_launch):
+            return None
+        return float(t["fetch_size_kb"]) * 1024.0 * float(t["fetch_correction"]) + float(t["write_size_kb"]) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(budget_s):
     """Same pipe on ONE host core: the real reference decimator (oracle/_ref, EO1 build of
     Decimators::decimate16_cen) + the oracle's pshufb CM256 encoder (cm256cc itself is absent:
@@ -175,7 +188,7 @@ def main():
                        "nb_fec": NB_FEC, "hb_variant": "EO1", "frames_per_stream_per_step": frames // max(args.steps, 1), "output": "zero-copy view of the frame area",
                        "parallelism": "stream-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(per_launch_samples),
                          "kernel": "decim_kernel<L=4,FC=cen,PACK16>", "launches": dec_n, "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": BYTES_DECIM * per_launch_samples,
                          "pipe_gbps_config3": round(BYTES_CONFIG3 * value * 1e6 / 1e9 / world, 1),
