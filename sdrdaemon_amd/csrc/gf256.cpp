@@ -55,6 +55,31 @@ void cm256_encode_matrix(int k, int rows, uint8_t *m)
         for (int j = 0; j < k; ++j) m[r * k + j] = g.matrix_element((uint8_t)(k + r), x_0, (uint8_t)j);
 }
 
+static void kleaves(const uint8_t *g, int n, std::vector<uint8_t> &out)
+{
+    if (n == 1) { out.push_back(g[0]); return; }
+    const int h = n / 2;
+    kleaves(g, h, out);
+    kleaves(g + h, h, out);
+    uint8_t s[16];
+    for (int i = 0; i < h; ++i) s[i] = (uint8_t)(g[i] ^ g[h + i]);
+    kleaves(s, h, out);
+}
+
+void cm256_karatsuba_leaf_tables(uint8_t *out)
+{
+    const GF256 &f = gf();
+    std::vector<uint8_t> all(256 * 32);
+    gf_build_tables(all.data());
+    for (int b = 0; b < 8; ++b) {
+        uint8_t g[16];
+        for (int u = 0; u < 16; ++u) g[u] = f.inv[128 ^ (16 * b + u)];
+        std::vector<uint8_t> lv;
+        kleaves(g, 16, lv);
+        for (size_t i = 0; i < lv.size(); ++i) memcpy(out + ((size_t)b * 81 + i) * 32, &all[(size_t)lv[i] * 32], 32);
+    }
+}
+
 int cm256_decode_plan(int k, int recovery_count_param, const uint8_t *indices, int *n_rec_out, uint8_t *rec_pos,
                       uint8_t *erased, uint8_t *coef)
 {

@@ -34,6 +34,11 @@ int gf_build_tables(uint8_t *tab);
 // rows x k encode matrix of cm256_encode (row r <-> recovery block index k + r)
 void cm256_encode_matrix(int k, int rows, uint8_t *m /* rows * k */);
 
+// Karatsuba leaf constants of the structured k = 128 encoder (gf_kernels.hip): for b = 0..7 the
+// 81 leaves, in depth-first (lo, hi, lo ^ hi) order, of the 16-point kernel G_b[u] = 1 / (128 ^ (16 b + u)),
+// each as its 32-byte multiplier table (layout of gf_build_tables).
+void cm256_karatsuba_leaf_tables(uint8_t *out /* 8 * 81 * 32 */);
+
 // Decode plan for one frame, restating CM256Decoder::Initialize + Decode/DecodeM1:
 // `indices` are the Index fields of the k descriptors in array order.  On success
 //   n_rec         number of recovery descriptors (= erasures repaired)

@@ -142,6 +142,153 @@ __global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Structured encoder for OriginalCount = 128 (the only geometry sdrdaemon uses, UDPSinkFEC.h:57).
+//
+// The Cauchy element (y_j ^ x_0) / (x_i ^ y_j) with x_0 = 128, x_i = 128 + r, y_j = j is
+//     M[r][j] = (128 ^ j) / (128 ^ (r ^ j)) = 1 ^ r * G[r ^ j],      G[t] = 1 / (128 ^ t)
+// (because (128 ^ j) ^ (128 ^ (r ^ j)) = r), hence
+//     recovery_r = P ^ r * (G (*) x)[r],   P = XOR of the 128 originals,
+// where (*) is an XOR-convolution over the block index: (G (*) x)[r] = XOR_j G[r ^ j] x_j.  Splitting
+// j = 32 jh + jl and r = 32 t + rl turns it into 32-point dyadic convolutions with the kernel blocks
+// G_b[u] = G[32 b + u], b = t ^ jh, and over a field of characteristic 2 those obey a Karatsuba rule
+//     y_lo = g_lo(*)z_lo ^ g_hi(*)z_hi,   y_hi = y_lo ^ (g_lo ^ g_hi)(*)(z_lo ^ z_hi)
+// (3 half-size products instead of 4).  Four levels on 16-point blocks: 81 constant multiplications +
+// 195 XORs per 16 x 16 block instead of 256 multiplications -- ~18 k lane-ops per 4-byte column of a
+// frame instead of 36 k for the generic kernel above.  One lane owns one 4-byte column of a frame (64
+// lanes x 2 waves = the 127 dwords of a block); the 243 leaf constants of each G_b come from the host
+// in depth-first order as ready-made 32-byte multiplier tables (immediate LDS offsets, no dependent loads).
+// Implementation: 16-point blocks (j = 16 cb + jl, r = 16 rt + rl, kernel block G_b[u] = G[16 b + u],
+// b = rt ^ cb; 81 leaves + 195 XORs per 16 x 16 block) keep the per-lane state at ~80 VGPRs.  A
+// workgroup = one (frame, half block) = 64 four-byte columns; its four waves take two column blocks
+// each, apply them to a pair of row tiles, XOR their partial sums into LDS (ds_xor), then each wave
+// finishes 8 of the 32 rows: recovery_r = P ^ r * c_r.  Leaf tables sit in LDS as {Ta, Tb} (16 B) +
+// {Tc} (4 B) arrays with immediate offsets: no dependent loads.
+__device__ __forceinline__ unsigned kmul(unsigned zval, const uint4_t &t, unsigned tc)
+{
+    const unsigned sa = zval & 0x07070707u, sb = (zval >> 3) & 0x07070707u, sc = (zval >> 6) & 0x03030303u;
+    return __builtin_amdgcn_perm(t.y, t.x, sa) ^ __builtin_amdgcn_perm(t.w, t.z, sb) ^ __builtin_amdgcn_perm(0u, tc, sc);
+}
+
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; // generic -> LDS byte address
+}
+
+constexpr int KN = 16;                                                                    // points per block
+constexpr int KLEAVES = 81;                                                               // 3^4
+__host__ __device__ constexpr int pow3(int n) { return n <= 1 ? 1 : 3 * pow3(n / 2); }    // leaves of an n-point node
+__host__ __device__ constexpr int sbase(int n) { return KN + (KN - n); }                  // scratch of the level of size n
+
+// y[YO .. YO+N) ^= g (*) v[ZO .. ZO+N); lt16 / lt4 = LDS byte addresses of the leaf tables of the block
+template <int N, int ZO, int YO, int LEAF0>
+__device__ __forceinline__ void acc_conv(unsigned (&v)[2 * KN - 1], unsigned (&y)[KN], unsigned lt16, unsigned lt4)
+{
+    if constexpr (N == 1) {
+        // The 81 table loads of a block have immediate addresses; left to the compiler they are all
+        // hoisted to the top (405 VGPRs of tables) and spilled.  An asm statement that loads one leaf's
+        // tables and waits for them keeps them in program order; the other waves of the SIMD cover the
+        // LDS latency (4-6 resident waves, 11 lane-ops per leaf each).
+        uint4_t t;
+        unsigned tc;
+        unsigned z = v[ZO]; // tied to the statement ("+v") so that its three selector dwords are formed here,
+                            // not when v[ZO] is produced (that alone tripled the live registers)
+        asm volatile("ds_read_b128 %0, %3 offset:%c5\n\tds_read_b32 %1, %4 offset:%c6\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(t), "=&v"(tc), "+v"(z)
+                     : "v"(lt16), "v"(lt4), "i"(LEAF0 * 16), "i"(LEAF0 * 4)
+                     : "memory");
+        y[YO] ^= kmul(z, t, tc);
+    } else {
+        constexpr int H = N / 2, L3 = pow3(H);
+#pragma unroll
+        for (int i = 0; i < H; ++i) y[YO + H + i] ^= y[YO + i];
+        acc_conv<H, ZO, YO, LEAF0>(v, y, lt16, lt4);
+        acc_conv<H, ZO + H, YO, LEAF0 + L3>(v, y, lt16, lt4);
+#pragma unroll
+        for (int i = 0; i < H; ++i) v[sbase(N) + i] = v[ZO + i] ^ v[ZO + H + i];
+        acc_conv<H, sbase(N), YO + H, LEAF0 + 2 * L3>(v, y, lt16, lt4);
+#pragma unroll
+        for (int i = 0; i < H; ++i) y[YO + H + i] ^= y[YO + i];
+    }
+}
+
+__global__ __launch_bounds__(GF_NT, 3) void gf_encode128_kernel(Enc128Args a)
+{
+    __shared__ __attribute__((aligned(16))) uint4_t lt16[8 * KLEAVES];  // {Ta, Tb} of the leaves of G_0..G_7
+    __shared__ unsigned lt4[8 * KLEAVES];                                // {Tc}
+    __shared__ __attribute__((aligned(16))) uint4_t rt16[128];          // tables of the row constants r < 128
+    __shared__ unsigned rt4[128];
+    __shared__ unsigned ysum[33][64];                                    // reduced convolution (32 rows) + parity (row 32)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 8 * KLEAVES; i += GF_NT) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(a.leaf_tables) + (size_t)i * 8;
+        lt16[i] = (uint4_t){src[0], src[1], src[2], src[3]};
+        lt4[i] = src[4];
+    }
+    if (tid < 128) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(a.tab) + (size_t)tid * 8;
+        rt16[tid] = (uint4_t){src[0], src[1], src[2], src[3]};
+        rt4[tid] = src[4];
+    }
+    for (int i = tid; i < 33 * 64; i += GF_NT) (&ysum[0][0])[i] = 0;
+    __syncthreads();
+
+    const int w = tid >> 6, lane = tid & 63;  // wave w owns column blocks 2w, 2w + 1
+    const int fi = blockIdx.x >> 1;
+    const int fr = a.frame_list ? a.frame_list[fi] : fi;
+    const int col = (blockIdx.x & 1) * 64 + lane;
+    const bool live = fr >= 0 && fr < a.nframes && col < 127;
+    const size_t frc = live ? (size_t)fr : 0;
+    const unsigned *src = reinterpret_cast<const unsigned *>(a.in + frc * a.in_frame_bytes) + 1 + (live ? col : 0);
+    unsigned *dst = reinterpret_cast<unsigned *>(a.out + frc * a.out_frame_bytes) + 1 + (live ? col : 0);
+
+    const int npairs = (a.rows + 31) / 32; // pairs of 16-row tiles
+#pragma unroll 1
+    for (int tp = 0; tp < npairs; ++tp) {
+        unsigned y0[KN], y1[KN];
+#pragma unroll
+        for (int i = 0; i < KN; ++i) { y0[i] = 0; y1[i] = 0; }
+        unsigned p = 0;
+#pragma unroll 1
+        for (int q = 0; q < 2; ++q) {
+            const int cb = 2 * w + q;
+            unsigned v[2 * KN - 1];
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < KN; ++i) v[i] = src[(size_t)(KN * cb + i) * 128];
+            } else {
+#pragma unroll
+                for (int i = 0; i < KN; ++i) v[i] = 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < KN; ++i) p ^= v[i];
+            const int b0 = (2 * tp) ^ cb, b1 = (2 * tp + 1) ^ cb;
+            acc_conv<KN, 0, 0, 0>(v, y0, lds_addr(lt16 + b0 * KLEAVES), lds_addr(lt4 + b0 * KLEAVES));
+            acc_conv<KN, 0, 0, 0>(v, y1, lds_addr(lt16 + b1 * KLEAVES), lds_addr(lt4 + b1 * KLEAVES));
+        }
+        if (tp == 0) __hip_atomic_fetch_xor(&ysum[32][lane], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int i = 0; i < KN; ++i) {
+            __hip_atomic_fetch_xor(&ysum[i][lane], y0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_xor(&ysum[KN + i][lane], y1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        // rows 8 w .. 8 w + 7 of the 32-row pair: recovery_r = P ^ r * c_r
+        const unsigned P = ysum[32][lane];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int rl = 8 * w + q, r = 32 * tp + rl;
+            if (r < a.rows && live) dst[(size_t)r * 128] = P ^ kmul(ysum[rl][lane], rt16[r], rt4[r]);
+        }
+        if (tp + 1 < npairs) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ysum[8 * w + q][lane] = 0;
+            __syncthreads();
+        }
+    }
+}
+
 // scatter copy of 508-byte blocks: dst[f][map[f][p]] = src[f][p] for map >= 0
 __global__ void block_scatter_kernel(const uint8_t *src, size_t src_frame_bytes, int src_pitch, int src_off, uint8_t *dst,
                                      size_t dst_frame_bytes, int dst_pitch, int dst_off, const int16_t *map, int nblocks,
@@ -177,6 +324,13 @@ hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream)
     if (ngroups <= 0) return hipSuccess;
     dim3 grid(ngroups, (a.rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
     hipLaunchKernelGGL(gf_apply_kernel, grid, dim3(GF_NT), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gf_encode128(const Enc128Args &a, hipStream_t stream)
+{
+    if (a.nlist <= 0 || a.rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gf_encode128_kernel, dim3(2 * a.nlist), dim3(GF_NT), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -107,6 +107,10 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
     cm256_encode_matrix(128, 128, em.data());
     if (hipMalloc(reinterpret_cast<void **>(&c->enc_matrix), em.size()) != hipSuccess ||
         hipMemcpy(c->enc_matrix, em.data(), em.size(), hipMemcpyHostToDevice) != hipSuccess) { delete c; return fail(SDRHIP_ENOMEM, "upload encode matrix"); }
+    std::vector<uint8_t> kl(8 * 81 * 32);
+    cm256_karatsuba_leaf_tables(kl.data());
+    if (hipMalloc(reinterpret_cast<void **>(&c->enc_leaves), kl.size()) != hipSuccess ||
+        hipMemcpy(c->enc_leaves, kl.data(), kl.size(), hipMemcpyHostToDevice) != hipSuccess) { delete c; return fail(SDRHIP_ENOMEM, "upload encoder constants"); }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
     *out = c;
     return SDRHIP_OK;
@@ -137,6 +141,7 @@ static void sdrhip::ctx_free(sdrhip_ctx *c)
     c->in.release(); c->out.release(); c->aux.release(); c->aux2.release(); c->aux3.release();
     if (c->gf_tab) (void)hipFree(c->gf_tab);
     if (c->enc_matrix) (void)hipFree(c->enc_matrix);
+    if (c->enc_leaves) (void)hipFree(c->enc_leaves);
     if (c->dec_coef) (void)hipFree(c->dec_coef);
     if (c->dec_dst) (void)hipFree(c->dec_dst);
     c->pin.release();

@@ -12,10 +12,33 @@ using namespace sdrhip;
 
 namespace sdrhip {
 
+// below this many recovery blocks the generic kernel (rows x 128 products) is cheaper than a full
+// 32-row Karatsuba tile (13.7 k lane-ops per column vs 36 k x rows / 32)
+constexpr int ENC128_MIN_ROWS = 13;
+
 int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
                       size_t rec_frame_bytes, const int32_t *frame_list_dev, int ngroups)
 {
     if (nframes == 0 || nb_fec <= 0) return SDRHIP_OK;
+    hipError_t e;
+    if (nb_fec >= ENC128_MIN_ROWS && rec_frame_bytes % 4 == 0 && frame_bytes % 4 == 0) {
+        // structured encoder (Karatsuba over the XOR-convolution form of the Cauchy rows); frame lists of
+        // the generic kernel come in groups of GF_FRAMES_PER_GROUP, this kernel takes them flat
+        Enc128Args k;
+        memset(&k, 0, sizeof(k));
+        k.in = frames; k.out = rec; k.tab = c->gf_tab; k.leaf_tables = c->enc_leaves;
+        k.in_frame_bytes = frame_bytes; k.out_frame_bytes = rec_frame_bytes;
+        k.rows = nb_fec; k.nframes = (int)nframes;
+        k.frame_list = frame_list_dev; k.nlist = frame_list_dev ? ngroups * GF_FRAMES_PER_GROUP : (int)nframes;
+        {
+            KTimer kt(c, SDRHIP_K_FEC_ENCODE);
+            e = launch_gf_encode128(k, c->stream);
+        }
+        if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec encode launch: %s", hipGetErrorString(e));
+        e = launch_fec_headers(frames, frame_bytes, rec, rec_frame_bytes, nb_fec, SDRHIP_NB_ORIGINAL, (int)nframes, c->stream);
+        if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec header launch: %s", hipGetErrorString(e));
+        return SDRHIP_OK;
+    }
     GfArgs a;
     memset(&a, 0, sizeof(a));
     a.in = frames; a.out = rec; a.coef = c->enc_matrix; a.tab = c->gf_tab;
@@ -24,7 +47,6 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
     a.rows = nb_fec; a.cols = SDRHIP_NB_ORIGINAL; a.coef_per_frame = 0;
     a.nframes = (int)nframes;
     a.frame_list = frame_list_dev; a.ngroups = ngroups;
-    hipError_t e;
     {
         KTimer kt(c, SDRHIP_K_FEC_ENCODE);
         e = launch_gf_apply(a, c->stream);

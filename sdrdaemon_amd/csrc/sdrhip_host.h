@@ -70,6 +70,7 @@ struct sdrhip_ctx {
     sdrhip::DevBuf in, out, aux, aux2, aux3; // staging for SDRHIP_MEM_HOST calls and FEC work areas
     uint8_t *gf_tab = nullptr;               // 256 x 32 B multiplier tables (device)
     uint8_t *enc_matrix = nullptr;           // 128 x 128 encode matrix, rows 128..255 (device)
+    uint8_t *enc_leaves = nullptr;           // Karatsuba leaf tables of the structured k = 128 encoder (device)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // decode-plan cache: erasure pattern (the 128 received block indices) -> matrix slot on the device
     static constexpr int DEC_SLOTS = 64;

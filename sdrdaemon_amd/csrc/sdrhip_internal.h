@@ -94,6 +94,21 @@ struct GfArgs {
     int matrix_rows;
 };
 hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream);
+
+// structured (Karatsuba) encoder for OriginalCount = 128: frames of 128 super blocks (pitch 512,
+// payload at +4) -> `rows` recovery super blocks (pitch 512, payload at +4)
+struct Enc128Args {
+    const uint8_t *in;
+    uint8_t *out;
+    const uint8_t *tab;             // 256 x 32 byte multiplier tables (device)
+    const uint8_t *leaf_tables;     // [8][81][32] multiplier tables of the Karatsuba leaves of G_0..G_7 (device)
+    size_t in_frame_bytes, out_frame_bytes;
+    int rows;                       // recovery blocks, 1..128
+    int nframes;                    // frames addressable through in/out
+    const int32_t *frame_list;      // optional list of frame indices (-1 = skip), nlist entries; NULL = 0..nlist-1
+    int nlist;
+};
+hipError_t launch_gf_encode128(const Enc128Args &a, hipStream_t stream);
 hipError_t launch_block_scatter(const uint8_t *src, size_t src_frame_bytes, int src_pitch, int src_off, uint8_t *dst,
                                 size_t dst_frame_bytes, int dst_pitch, int dst_off, const int16_t *map, int nblocks, int nframes,
                                 hipStream_t stream);

@@ -156,3 +156,18 @@ def test_decode_plan_cache_many_patterns(ctx, oracle):
         for f in range(30):
             assert np.array_equal(payload[f].view(np.int16).reshape(-1, 2), x[f * 16129:(f + 1) * 16129]), (call, f)
             assert np.array_equal(b0[f], frames[f, 0, 4:]), (call, f)
+
+
+@pytest.mark.parametrize("R", [1, 12, 13, 16, 17, 31, 32, 33, 64, 127, 128])
+def test_frame_encoder_every_row_count(ctx, oracle, R):
+    """nb_fec below 13 uses the generic kernel, from 13 on the structured (Karatsuba over the
+    XOR-convolution form of the Cauchy rows) one, in 16-row tiles: both must equal cm256_encode."""
+    import sdrdaemon_amd as sd
+
+    F = 5
+    x = signals.noise(F * 16129, 200 + R)
+    frames = oracle.framer(nb_fec_blocks=min(R, 127)).write(x)
+    frames[:, :, 3] = 0
+    rec = sd.fec_encode_frames(ctx, frames, R)
+    for f in range(F):
+        assert np.array_equal(rec[f], oracle.frame_encode(frames[f], R)), (R, f)
