@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--log2-samples", type=int, default=25, help="samples per stream per step (default 2^25)")
     ap.add_argument("--input", choices=["noise", "testsource"], default="noise")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to dry-run the N > 1 path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,8 +126,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+        if args.backend == "gloo":
+            local %= torch.cuda.device_count()  # dry run: ranks may share a GPU
+            torch.cuda.set_device(local)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
     else:
         dist = None
         torch.cuda.set_device(local)
@@ -168,7 +175,8 @@ def main():
     fec_ms, fec_n = ctx.kernel_timing_read(K_FEC_ENCODE)
     ctx.kernel_timing(False)
     # the only collectives of the job: MAX of the elapsed time, SUM of the samples (8 bytes each, reporting only)
-    elapsed, total_samples = sharding.aggregate(elapsed, float(S) * n * args.steps, dist, dev)
+    elapsed, total_samples = sharding.aggregate(elapsed, float(S) * n * args.steps, dist,
+                                                dev if args.backend == "nccl" else torch.device("cpu"))
 
     if rank == 0:
         value = total_samples / elapsed / 1e6
