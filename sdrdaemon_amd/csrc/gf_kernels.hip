@@ -241,6 +241,7 @@ __global__ __launch_bounds__(GF_NT, 3) void gf_encode128_kernel(Enc128Args a)
     const size_t frc = live ? (size_t)fr : 0;
     const unsigned *src = reinterpret_cast<const unsigned *>(a.in + frc * a.in_frame_bytes) + 1 + (live ? col : 0);
     unsigned *dst = reinterpret_cast<unsigned *>(a.out + frc * a.out_frame_bytes) + 1 + (live ? col : 0);
+    const unsigned hdr0 = (live && col == 0) ? src[-1] : 0u;
 
     const int npairs = (a.rows + 31) / 32; // pairs of 16-row tiles
 #pragma unroll 1
@@ -278,7 +279,11 @@ __global__ __launch_bounds__(GF_NT, 3) void gf_encode128_kernel(Enc128Args a)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int rl = 8 * w + q, r = 32 * tp + rl;
-            if (r < a.rows && live) dst[(size_t)r * 128] = P ^ kmul(ysum[rl][lane], rt16[r], rt4[r]);
+            if (r < a.rows && live) {
+                dst[(size_t)r * 128] = P ^ kmul(ysum[rl][lane], rt16[r], rt4[r]);
+                // header {frameIndex (of the frame's block 0), 128 + r, filler 0}, UDPSinkFEC.cpp:239-243
+                if (col == 0) dst[(size_t)r * 128 - 1] = (hdr0 & 0xffffu) | ((unsigned)(128 + r) << 16);
+            }
         }
         if (tp + 1 < npairs) {
             __syncthreads();
@@ -304,13 +309,16 @@ __global__ void block_scatter_kernel(const uint8_t *src, size_t src_frame_bytes,
     store_slab(dst + (size_t)f * dst_frame_bytes + (size_t)d * dst_pitch + dst_off, l, v);
 }
 
-// headers of the recovery super blocks: {frameIndex (from block 0 of the frame), 128 + r, 0}
+// headers of the recovery super blocks: {frameIndex (from block 0 of the frame), 128 + r, 0}; generic
+// encoder only (gf_encode128_kernel writes them itself).  frame_list as in GfArgs (flat, -1 = none).
 __global__ void fec_header_kernel(const uint8_t *frames, size_t in_frame_bytes, uint8_t *rec, size_t out_frame_bytes, int nb_fec,
-                                  int first_index, int nframes)
+                                  int first_index, int nframes, const int32_t *frame_list, int nlist)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nframes * nb_fec) return;
-    const int f = i / nb_fec, r = i - f * nb_fec;
+    if (i >= nlist * nb_fec) return;
+    const int fi = i / nb_fec, r = i - fi * nb_fec;
+    const int f = frame_list ? frame_list[fi] : fi;
+    if (f < 0 || f >= nframes) return;
     const unsigned h0 = *reinterpret_cast<const unsigned *>(frames + (size_t)f * in_frame_bytes);
     *reinterpret_cast<unsigned *>(rec + (size_t)f * out_frame_bytes + (size_t)r * 512) = (h0 & 0xffffu) | ((unsigned)(first_index + r) << 16);
 }
@@ -346,12 +354,13 @@ hipError_t launch_block_scatter(const uint8_t *src, size_t src_frame_bytes, int 
 }
 
 hipError_t launch_fec_headers(const uint8_t *frames, size_t in_frame_bytes, uint8_t *rec, size_t out_frame_bytes, int nb_fec,
-                              int first_index, int nframes, hipStream_t stream)
+                              int first_index, int nframes, const int32_t *frame_list, int nlist, hipStream_t stream)
 {
-    if (nframes <= 0 || nb_fec <= 0) return hipSuccess;
-    int n = nframes * nb_fec;
+    if (!frame_list) nlist = nframes;
+    if (nlist <= 0 || nb_fec <= 0) return hipSuccess;
+    const int n = nlist * nb_fec;
     hipLaunchKernelGGL(fec_header_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, frames, in_frame_bytes, rec, out_frame_bytes,
-                       nb_fec, first_index, nframes);
+                       nb_fec, first_index, nframes, frame_list, nlist);
     return hipGetLastError();
 }
 

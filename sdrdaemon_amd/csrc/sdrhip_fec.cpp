@@ -35,9 +35,7 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
             e = launch_gf_encode128(k, c->stream);
         }
         if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec encode launch: %s", hipGetErrorString(e));
-        e = launch_fec_headers(frames, frame_bytes, rec, rec_frame_bytes, nb_fec, SDRHIP_NB_ORIGINAL, (int)nframes, c->stream);
-        if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec header launch: %s", hipGetErrorString(e));
-        return SDRHIP_OK;
+        return SDRHIP_OK; // (the kernel writes the recovery block headers as well)
     }
     GfArgs a;
     memset(&a, 0, sizeof(a));
@@ -53,7 +51,8 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec encode launch: %s", hipGetErrorString(e));
     // headers {frameIndex, 128 + r, filler 0} of the recovery super blocks (UDPSinkFEC.cpp:239-243)
-    e = launch_fec_headers(frames, frame_bytes, rec, rec_frame_bytes, nb_fec, SDRHIP_NB_ORIGINAL, (int)nframes, c->stream);
+    e = launch_fec_headers(frames, frame_bytes, rec, rec_frame_bytes, nb_fec, SDRHIP_NB_ORIGINAL, (int)nframes, frame_list_dev,
+                           ngroups * GF_FRAMES_PER_GROUP, c->stream);
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec header launch: %s", hipGetErrorString(e));
     return SDRHIP_OK;
 }

@@ -113,6 +113,6 @@ hipError_t launch_block_scatter(const uint8_t *src, size_t src_frame_bytes, int 
                                 size_t dst_frame_bytes, int dst_pitch, int dst_off, const int16_t *map, int nblocks, int nframes,
                                 hipStream_t stream);
 hipError_t launch_fec_headers(const uint8_t *frames, size_t in_frame_bytes, uint8_t *rec, size_t out_frame_bytes, int nb_fec,
-                              int first_index, int nframes, hipStream_t stream);
+                              int first_index, int nframes, const int32_t *frame_list, int nlist, hipStream_t stream);
 
 } // namespace sdrhip

@@ -126,16 +126,18 @@ struct sdrhip_rx {
     int nstreams;
     sdrhip_rx_config cfg;
     sdrhip_decimators *dec;
-    DevBuf work;              // [nstreams][cap_frames][128 + nb_fec][512]
+    // [nstreams][cap_frames][128 + nb_fec][512].  A call fills slots base_slot .. base_slot + done of
+    // every stream; slot base_slot + done (the frame still being filled) is slot base_slot of the next
+    // call, so the window slides and nothing is copied until it reaches the end of the area.
+    DevBuf work;
     size_t cap_frames;        // frame slots per stream in `work`
-    uint64_t pending_samples; // decimated samples sitting in slot 0 (the partial frame)
-    bool frame_open;          // slot 0 has its meta block (a frame was started)
-    uint16_t frame_count;     // m_frameCount of slot 0
-    DevBuf meta;              // 24-byte meta record (device)
-    DevBuf pending;           // [nstreams][128 + nb_fec][512]: the partial frame between calls
-    PinnedBuf meta_pin;
-    size_t view_frames = 0;   // finished frames of the last call, readable in `work`
-    DevBuf flist;             // frame list of the encode launch (device)
+    size_t base_slot;         // slot of the frame being filled
+    uint64_t pending_samples; // decimated samples sitting in that slot (the partial frame)
+    bool frame_open;          // it has its meta block (a frame was started)
+    uint16_t frame_count;     // its m_frameCount
+    size_t view_slot = 0;     // finished frames of the last call: slots view_slot .. view_slot + view_frames
+    size_t view_frames = 0;
+    DevBuf flist;             // frame list of the encode launch (device), relative to the window
     std::vector<int32_t> flist_host;
     size_t flist_done = 0, flist_cap = 0;
 };
@@ -152,10 +154,9 @@ extern "C" int sdrhip_rx_create(sdrhip_ctx *ctx, int nstreams, const sdrhip_rx_c
     sdrhip_rx *rx = new (std::nothrow) sdrhip_rx();
     if (!rx) return fail(SDRHIP_ENOMEM, "out of host memory");
     rx->ctx = ctx; rx->nstreams = nstreams; rx->cfg = *cfg; rx->dec = nullptr;
-    rx->cap_frames = 0; rx->pending_samples = 0; rx->frame_open = false; rx->frame_count = 0;
+    rx->cap_frames = 0; rx->base_slot = 0; rx->pending_samples = 0; rx->frame_open = false; rx->frame_count = 0;
     int rc = sdrhip_decimators_create(ctx, nstreams, cfg->hb_variant, &rx->dec);
     if (rc) { delete rx; return rc; }
-    if ((rc = rx->meta.reserve(64))) { sdrhip_decimators_destroy(rx->dec); delete rx; return rc; }
     *out = rx;
     return SDRHIP_OK;
 }
@@ -165,17 +166,14 @@ extern "C" void sdrhip_rx_destroy(sdrhip_rx *rx)
     if (!rx) return;
     sdrhip_decimators_destroy(rx->dec);
     rx->work.release();
-    rx->meta.release();
     rx->flist.release();
-    rx->pending.release();
-    rx->meta_pin.release();
     delete rx;
 }
 
 extern "C" int sdrhip_rx_frames_view(const sdrhip_rx *rx, const uint8_t **base, size_t *stream_stride_bytes, size_t *n_frames)
 {
     if (!rx || !base || !stream_stride_bytes || !n_frames) return fail(SDRHIP_EINVAL, "rx_frames_view: NULL argument");
-    *base = rx->work.as<uint8_t>();
+    *base = rx->work.as<uint8_t>() + rx->view_slot * (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
     *stream_stride_bytes = rx->cap_frames * (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
     *n_frames = rx->view_frames;
     return SDRHIP_OK;
@@ -221,22 +219,32 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         return fail(SDRHIP_EINVAL, "mem must be SDRHIP_MEM_HOST or SDRHIP_MEM_DEVICE");
     }
 
-    // ---- work area [stream][slot][128 + R][512]: slot 0 = the frame being filled (it waits in
-    // `pending` between calls, so that the finished frames of a call stay readable in place until the
-    // next call: sdrhip_rx_frames_view), grows to done + 1 slots
+    // ---- work area [stream][slot][128 + R][512]: this call fills slots base_slot .. base_slot + done.  The
+    // finished frames stay readable in place until the next call (sdrhip_rx_frames_view); the frame still
+    // being filled is the first slot of the next call.  At the end of the area the window wraps: the open
+    // frame moves to slot 0 (one strided copy every few calls instead of a save + restore per call).
     const size_t need = done + 1;
-    if (need > rx->cap_frames) {
-        HIP_TRY(hipStreamSynchronize(c->stream)); // earlier launches may still use the old area
-        const size_t ncap = need + need / 2;
-        rx->work.release();
-        if ((rc = rx->work.reserve((size_t)S * ncap * frame_bytes))) { rx->cap_frames = 0; return rc; }
-        rx->cap_frames = ncap;
+    if (rx->base_slot + need > rx->cap_frames) {
+        if (need > rx->cap_frames) {
+            DevBuf bigger;
+            const size_t ncap = 4 * need;
+            if ((rc = bigger.reserve((size_t)S * ncap * frame_bytes))) return rc;
+            if (rx->frame_open)
+                HIP_TRY(hipMemcpy2DAsync(bigger.p, ncap * frame_bytes, rx->work.as<uint8_t>() + rx->base_slot * frame_bytes,
+                                         rx->cap_frames * frame_bytes, frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream)); // earlier launches may still use the old area
+            rx->work.release();
+            rx->work = bigger;
+            rx->cap_frames = ncap;
+        } else if (rx->frame_open) {
+            uint8_t *w0 = rx->work.as<uint8_t>();
+            HIP_TRY(hipMemcpy2DAsync(w0, rx->cap_frames * frame_bytes, w0 + rx->base_slot * frame_bytes, rx->cap_frames * frame_bytes,
+                                     frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
+        }
+        rx->base_slot = 0;
     }
-    if ((rc = rx->pending.reserve((size_t)S * frame_bytes))) return rc;
-    uint8_t *work = rx->work.as<uint8_t>();
     const size_t stream_bytes = rx->cap_frames * frame_bytes;
-    if (rx->frame_open)
-        HIP_TRY(hipMemcpy2DAsync(work, stream_bytes, rx->pending.p, frame_bytes, frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
+    uint8_t *work = rx->work.as<uint8_t>() + rx->base_slot * frame_bytes; // slot 0 of the window
 
     // ---- decimate straight into the frame layout
     unsigned ss = rx->cfg.sample_bits;
@@ -264,12 +272,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         }
         crc ^= 0xFFFFFFFFu;
         memcpy(m + 20, &crc, 4);
-        if ((rc = rx->meta_pin.reserve(32))) return rc; // waits for the previous call's upload, long done
-        memcpy(rx->meta_pin.p, m, 24);
-        HIP_TRY(hipMemcpyAsync(rx->meta.p, rx->meta_pin.p, 24, hipMemcpyHostToDevice, c->stream));
-        rx->meta_pin.mark(c->stream);
-        hipError_t e = launch_frame_meta(work, stream_bytes, FB, S, first_new, started, (unsigned)rx->frame_count + first_new,
-                                         rx->meta.as<uint8_t>(), c->stream);
+        hipError_t e = launch_frame_meta(work, stream_bytes, FB, S, first_new, started, (unsigned)rx->frame_count + first_new, m, c->stream);
         if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "frame meta launch: %s", hipGetErrorString(e));
     }
 
@@ -293,10 +296,9 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     if (done && frames_out)
         HIP_TRY(hipMemcpy2DAsync(frames_out, S > 1 ? frame_stride_bytes : done * frame_bytes, work, stream_bytes, done * frame_bytes, S,
                                  mem == SDRHIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
-    // the frame still being filled waits in `pending`
-    if (rest > 0)
-        HIP_TRY(hipMemcpy2DAsync(rx->pending.p, frame_bytes, work + done * frame_bytes, stream_bytes, frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
+    rx->view_slot = rx->base_slot;
     rx->view_frames = done;
+    rx->base_slot += done; // the frame still being filled opens the next call's window
     rx->pending_samples = rest;
     rx->frame_open = rest > 0;
     rx->frame_count = (uint16_t)(rx->frame_count + done);
