@@ -196,3 +196,33 @@ def test_rx_zero_copy_view_equals_copy(ctx, oracle):
         assert torch.equal(fa, fb), i
         total += fa.shape[1]
     assert total == 5
+
+
+def test_rx_pipe_window_wraps_and_grows(ctx, oracle):
+    """Many calls on one pipe: the sliding frame window of the work area wraps (open frame moves to
+    slot 0) and grows (open frame moves to the new area); frames must stay those of the reference chain."""
+    import sdrdaemon_amd as sd
+
+    S, log2, R = 2, 1, 16
+    per_frame = 16129 << log2
+    sizes = [per_frame // 2, per_frame, per_frame, per_frame + 2, per_frame - 2, per_frame, 3 * per_frame // 2,
+             6 * per_frame + 10, per_frame // 4, 9 * per_frame, per_frame, per_frame, 2 * per_frame]
+    x = np.stack([signals.noise(sum(sizes), 90 + s) for s in range(S)])
+    rx = sd.RxPipe(ctx, S, log2decim=log2, nb_fec=R)
+    ods = [oracle.decimators(0) for _ in range(S)]
+    frs = [oracle.framer(nb_fec_blocks=R, sample_bytes=2, sample_bits=16) for _ in range(S)]
+    pos, nframes = 0, 0
+    for i, n in enumerate(sizes):
+        seg = np.ascontiguousarray(x[:, pos:pos + n])
+        pos += n
+        got = rx.process(seg, tv_sec=i, tv_usec=0)
+        for s in range(S):
+            y, _ = ods[s].decimate(log2, 2, 16, seg[s])
+            frs[s].s.tv_sec, frs[s].s.tv_usec = i, 0
+            e = frs[s].write(y)
+            assert got.shape[1] == e.shape[0], (i, s)
+            for f in range(e.shape[0]):
+                assert np.array_equal(got[s, f, :128], e[f]), (i, s, f)
+                assert np.array_equal(got[s, f, 128:], oracle.frame_encode(e[f], R)), (i, s, f)
+        nframes += got.shape[1]
+    assert nframes == sum(sizes) // per_frame
