@@ -12,6 +12,11 @@ samples = 1 GiB of int16 IQ per GPU and step, resident in HBM before the timed r
 A step = one sdrhip_rx_process() call over that batch (decimate -> frame -> encode); the
 streams are continuous across steps (filter state and partial frames carry over).
 
+Before the W warm-up steps the same step is run untimed for --preroll-seconds (default 0.25 s):
+the GPU's clocks ramp over the first ~60 ms of load (measured: 0.69 ms/step right after start,
+0.59 ms/step from ~60 ms on, flat over 2000 steps), which a small W would otherwise put into
+the timed region.  The timed region is exactly K steps between barrier + synchronize pairs.
+
 One JSON line on rank 0; `value` = whole-job M input samples / s.
 """
 import argparse
@@ -110,11 +115,16 @@ def cpu_baseline(budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2-samples", type=int, default=25, help="samples per stream per step (default 2^25)")
     ap.add_argument("--input", choices=["noise", "testsource"], default="noise")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--preroll-seconds", type=float, default=0.25,
+                    help="untimed run-in of the same step before the W warm-up steps (the GPU's clocks ramp over the first "
+                         "~60 ms of load: with a small W the timed steps would measure that ramp)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="diagnostic: leave the per-kernel HIP events out of the timed region (roofline fields become null)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to dry-run the N > 1 path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -156,10 +166,17 @@ def main():
         # the way transmitUDP sends straight out of m_txBlocks (UDPSinkFEC.cpp:259-282)
         return rx.process_view(x, tv_sec=i, tv_usec=0)
 
+    preroll = 0
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.preroll_seconds:
+        for _ in range(10):
+            step(0)
+        torch.cuda.synchronize()
+        preroll += 10
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    ctx.kernel_timing(True)
+    ctx.kernel_timing(not args.no_kernel_timing)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -181,11 +198,12 @@ def main():
     if rank == 0:
         value = total_samples / elapsed / 1e6
         per_launch_samples = float(S) * n
-        avg_ms = dec_ms / max(dec_n, 1)
+        avg_ms = dec_ms / max(dec_n, 1) if dec_n else float("nan")
         achieved = BYTES_DECIM * per_launch_samples / (avg_ms * 1e-3) / 1e9
         res = {
             "metric": "IQ Msamples/s through decim+FEC-encode pipe; bit-exact vs CPU ref",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "preroll_steps": preroll,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32",
             "data": "synthetic: %s, %d streams/GPU (stream id = rank*%d + s), HBM-resident before the timed region" %
