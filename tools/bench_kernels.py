@@ -18,9 +18,13 @@ g = torch.Generator(device=dev).manual_seed(1)
 S = 8
 
 
-def timed(cls, fn, reps=5):
-    fn()
-    ctx.synchronize()
+def timed(cls, fn, reps=20, preroll_s=0.15):
+    import time
+
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < preroll_s:  # clocks ramp over the first ~60 ms of load
+        fn()
+        ctx.synchronize()
     ctx.kernel_timing(True)
     for _ in range(reps):
         fn()
