@@ -66,6 +66,21 @@ def pmc_traffic(samples_per_launch):
         return None
 
 
+VALU_PEAK_TLANEOPS = 1024 * 16 * 2.4e9 / 1e12  # 1024 SIMDs x 16 integer lanes / clk x 2.4 GHz
+
+
+def pmc_valu_lane_ops(samples_per_launch):
+    """integer VALU lane-ops per launch of the decimator kernel (SQ_INSTS_VALU x 64, committed PMC pass)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)["decim_kernel<4,2,true>"]
+        if int(t["samples_per_launch"]) != int(samples_per_launch):
+            return None
+        return float(t["valu_wave_insts"]) * 64.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(budget_s):
     """Same pipe on ONE host core: the real reference decimator (oracle/_ref, EO1 build of
     Decimators::decimate16_cen) + the oracle's pshufb CM256 encoder (cm256cc itself is absent:
@@ -220,6 +235,12 @@ def main():
                          "pipe_gbps_config3": round(BYTES_CONFIG3 * value * 1e6 / 1e9 / world, 1),
                          "fec_encode_avg_launch_ms": round(fec_ms / max(fec_n, 1), 4), "fec_encode_launches": fec_n},
         }
+        lane_ops = pmc_valu_lane_ops(per_launch_samples)
+        if lane_ops and dec_n:
+            # the ceiling that actually binds K1 (secondary figure of SURVEY.md 8d): integer VALU issue
+            tl = lane_ops / (avg_ms * 1e-3) / 1e12
+            res["roofline"]["valu"] = {"achieved": round(tl, 2), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "T lane-ops/s",
+                                       "frac": round(tl / VALU_PEAK_TLANEOPS, 4), "lane_ops_per_sample": round(lane_ops / per_launch_samples, 2)}
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             res["gpu_over_cpu_1core"] = round(value / res["cpu_baseline"]["value"], 1)
