@@ -68,6 +68,15 @@ __device__ __forceinline__ int dot2(unsigned a, unsigned taps, int acc)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, taps), acc, false);
 }
 
+// first link of a dot2 chain: the three-address form (d = a . b + c) takes the chain's initial value from a
+// VGPR that stays put; hipcc only emits the accumulate-in-place v_dot2c and a v_mov per chain in front of it
+__device__ __forceinline__ int dot2_init(unsigned a, unsigned taps, int c)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(taps), "v"(c));
+    return d;
+}
+
 // one v_mad_i32_i24 (hipcc otherwise splits the FIR into v_mul_i32_i24 + v_add3_u32 trees,
 // ~25 % more lane-ops).  The tap is wave-uniform: one SGPR operand, within the constant-bus limit.
 __device__ __forceinline__ int mad24(int a, int tap, int acc)
@@ -137,15 +146,16 @@ template <class G, int S> __device__ __forceinline__ void run_stage(int *lds, in
             uint4_t v = *reinterpret_cast<const uint4_t *>(pe + k0 / 2 + 8 + d);
             we[d] = v.x; we[d + 1] = v.y; we[d + 2] = v.z; we[d + 3] = v.w;
         }
+        const int bias13 = bias << 13;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            int acc = bias << 13;
+            int acc;
             if (r & 1) { // window entries r+1 .. r+32 = dwords (r+1)/2 ..; entry x <-> tap 32 + r - x
-                acc = dot2(we[(r + 1) / 2], pack_taps(8192, 0), acc);
+                acc = dot2_init(we[(r + 1) / 2], pack_taps(8192, 0), bias13);
 #pragma unroll
                 for (int p = 0; p < 16; ++p) acc = dot2(wo[(r + 1) / 2 + p], pack_taps(H32(31 - 2 * p), H32(30 - 2 * p)), acc);
             } else {
-                acc = dot2(we[r / 2], pack_taps(0, 8192), acc);
+                acc = dot2_init(we[r / 2], pack_taps(0, 8192), bias13);
                 acc = dot2(wo[r / 2], pack_taps(0, H32(31)), acc);
 #pragma unroll
                 for (int p = 1; p < 16; ++p) acc = dot2(wo[r / 2 + p], pack_taps(H32(32 - 2 * p), H32(31 - 2 * p)), acc);
