@@ -173,6 +173,13 @@ typedef struct {
 typedef struct sdrhip_rx sdrhip_rx;
 int sdrhip_rx_create(sdrhip_ctx *ctx, int nstreams, const sdrhip_rx_config *cfg, sdrhip_rx **out);
 void sdrhip_rx_destroy(sdrhip_rx *rx);
+/* Live reconfiguration between two sdrhip_rx_process calls, the way sdrdaemonrx applies a control
+ * message (Downsampler::configure, Downsampler.cpp:32-67: decim / fcpos; UDPSink::setNbBlocksFEC,
+ * setCenterFrequency, setSampleRate, sdrdaemonrx.cpp:300-340).  As in the reference the filter
+ * states carry over (the six half-band instances are shared by every decimateN entry point), the
+ * frame being filled keeps the meta block it was started with and is encoded with the fecblk value
+ * in force when it completes (UDPSinkFEC.cpp:160-165).  hb_variant cannot change. */
+int sdrhip_rx_reconfigure(sdrhip_rx *rx, const sdrhip_rx_config *cfg);
 /* Feeds n_in device-rate samples per stream.  Completed frames of stream s are written to
  * frames_out + s*frame_stride_bytes as (128 + nb_fec) super blocks of 512 bytes each,
  * frame after frame; *n_frames (per stream, identical for all streams) is the number of

@@ -27,7 +27,7 @@ EXPORTS = [
     "sdrhip_ctx_timing_begin", "sdrhip_ctx_timing_end", "sdrhip_ctx_kernel_timing", "sdrhip_ctx_kernel_timing_read", "sdrhip_decimators_create", "sdrhip_decimators_destroy",
     "sdrhip_decimators_reset", "sdrhip_decimate", "sdrhip_interpolators_create", "sdrhip_interpolators_destroy",
     "sdrhip_interpolators_reset", "sdrhip_interpolate", "sdrhip_cm256_encode", "sdrhip_cm256_decode",
-    "sdrhip_fec_encode_frames", "sdrhip_fec_decode_frames", "sdrhip_rx_create", "sdrhip_rx_destroy", "sdrhip_rx_process",
+    "sdrhip_fec_encode_frames", "sdrhip_fec_decode_frames", "sdrhip_rx_create", "sdrhip_rx_destroy", "sdrhip_rx_reconfigure", "sdrhip_rx_process",
     "sdrhip_rx_max_frames", "sdrhip_rx_frames_view", "sdrhip_tx_create", "sdrhip_tx_destroy", "sdrhip_tx_process",
 ]
 
@@ -83,6 +83,7 @@ def load():
     lib.sdrhip_fec_decode_frames.argtypes = [vp, vp, vp, sz, vp, vp, i]
     lib.sdrhip_rx_create.argtypes = [vp, i, C.POINTER(RxConfig), C.POINTER(vp)]
     lib.sdrhip_rx_destroy.argtypes = [vp]
+    lib.sdrhip_rx_reconfigure.argtypes = [vp, C.POINTER(RxConfig)]
     lib.sdrhip_rx_destroy.restype = None
     lib.sdrhip_rx_process.argtypes = [vp, vp, sz, sz, C.c_uint32, C.c_uint32, vp, sz, C.POINTER(sz), i]
     lib.sdrhip_rx_frames_view.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]

@@ -142,15 +142,15 @@ struct sdrhip_rx {
     size_t flist_done = 0, flist_cap = 0;
 };
 
+static int rx_check_config(const sdrhip_rx_config *cfg);
+
 extern "C" int sdrhip_rx_create(sdrhip_ctx *ctx, int nstreams, const sdrhip_rx_config *cfg, sdrhip_rx **out)
 {
     if (!ctx || !cfg || !out || nstreams <= 0) return fail(SDRHIP_EINVAL, "rx_create: bad argument");
-    if (cfg->log2decim < 0 || cfg->log2decim > 6) return fail(SDRHIP_EINVAL, "Invalid log2 decimation factor");
-    if (cfg->fcpos < 0 || cfg->fcpos > 2) return fail(SDRHIP_EINVAL, "Invalid Fc position index");
-    if (cfg->nb_fec < 0 || cfg->nb_fec > 128) return fail(SDRHIP_EINVAL, "nb_fec must be 0..128");
-    if (cfg->sample_bits < 1 || cfg->sample_bits > 16) return fail(SDRHIP_EINVAL, "sample_bits must be 1..16");
-    if (cfg->log2decim == 0 || (cfg->fcpos != SDRHIP_FC_CEN && cfg->log2decim <= 2))
-        return fail(SDRHIP_EINVAL, "rx pipe: the filter-less settings (decim 0, inf/sup 1-2) are not fused; use sdrhip_decimate + sdrhip_fec_encode_frames");
+    {
+        const int rcc = rx_check_config(cfg);
+        if (rcc) return rcc;
+    }
     sdrhip_rx *rx = new (std::nothrow) sdrhip_rx();
     if (!rx) return fail(SDRHIP_ENOMEM, "out of host memory");
     rx->ctx = ctx; rx->nstreams = nstreams; rx->cfg = *cfg; rx->dec = nullptr;
@@ -158,6 +158,47 @@ extern "C" int sdrhip_rx_create(sdrhip_ctx *ctx, int nstreams, const sdrhip_rx_c
     int rc = sdrhip_decimators_create(ctx, nstreams, cfg->hb_variant, &rx->dec);
     if (rc) { delete rx; return rc; }
     *out = rx;
+    return SDRHIP_OK;
+}
+
+static int rx_check_config(const sdrhip_rx_config *cfg)
+{
+    if (cfg->log2decim < 0 || cfg->log2decim > 6) return fail(SDRHIP_EINVAL, "Invalid log2 decimation factor");
+    if (cfg->fcpos < 0 || cfg->fcpos > 2) return fail(SDRHIP_EINVAL, "Invalid Fc position index");
+    if (cfg->nb_fec < 0 || cfg->nb_fec > 128) return fail(SDRHIP_EINVAL, "nb_fec must be 0..128");
+    if (cfg->sample_bits < 1 || cfg->sample_bits > 16) return fail(SDRHIP_EINVAL, "sample_bits must be 1..16");
+    if (cfg->log2decim == 0 || (cfg->fcpos != SDRHIP_FC_CEN && cfg->log2decim <= 2))
+        return fail(SDRHIP_EINVAL, "rx pipe: the filter-less settings (decim 0, inf/sup 1-2) are not fused; use sdrhip_decimate + sdrhip_fec_encode_frames");
+    return SDRHIP_OK;
+}
+
+extern "C" int sdrhip_rx_reconfigure(sdrhip_rx *rx, const sdrhip_rx_config *cfg)
+{
+    if (!rx || !cfg) return fail(SDRHIP_EINVAL, "rx_reconfigure: NULL argument");
+    int rc = rx_check_config(cfg);
+    if (rc) return rc;
+    if (cfg->hb_variant != rx->cfg.hb_variant) return fail(SDRHIP_EINVAL, "rx_reconfigure: hb_variant is fixed at creation");
+    sdrhip_ctx *c = rx->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    if (cfg->nb_fec != rx->cfg.nb_fec && rx->cap_frames) {
+        // the slots change size: the frame being filled (its 128 original super blocks) moves to slot 0 of a new area
+        const int S = rx->nstreams;
+        const size_t old_fb = (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
+        const size_t new_fb = (size_t)(SDRHIP_NB_ORIGINAL + cfg->nb_fec) * SDRHIP_UDPSIZE;
+        DevBuf fresh;
+        if ((rc = fresh.reserve((size_t)S * rx->cap_frames * new_fb))) return rc;
+        if (rx->frame_open)
+            HIP_TRY(hipMemcpy2DAsync(fresh.p, rx->cap_frames * new_fb, rx->work.as<uint8_t>() + rx->base_slot * old_fb,
+                                     rx->cap_frames * old_fb, (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE, S, hipMemcpyDeviceToDevice,
+                                     c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream)); // earlier launches may still use the old area
+        rx->work.release();
+        rx->work = fresh;
+        rx->base_slot = 0;
+        rx->view_slot = 0;
+        rx->view_frames = 0;
+    }
+    rx->cfg = *cfg;
     return SDRHIP_OK;
 }
 

@@ -368,7 +368,48 @@ class RxPipe:
         self.ctx, self.nstreams, self.nb_fec = ctx, nstreams, nb_fec
         self.cfg = RxConfig(log2decim, fcpos, hb_variant, sample_bits, nb_fec, center_frequency_khz, sample_rate)
         self.h = C.c_void_p()
+        self.m_error = ""
         check(ctx.lib.sdrhip_rx_create(ctx.h, nstreams, C.byref(self.cfg), C.byref(self.h)))
+
+    def error(self):
+        e, self.m_error = self.m_error, ""
+        return e
+
+    def reconfigure(self, **kw):
+        """Live change between two process() calls (sdrhip_rx_reconfigure): any of log2decim, fcpos,
+        sample_bits, nb_fec, center_frequency_khz, sample_rate."""
+        cfg = RxConfig(self.cfg.log2decim, self.cfg.fcpos, self.cfg.hb_variant, self.cfg.sample_bits, self.cfg.nb_fec,
+                       self.cfg.center_frequency_khz, self.cfg.sample_rate)
+        for k, v in kw.items():
+            if k not in ("log2decim", "fcpos", "sample_bits", "nb_fec", "center_frequency_khz", "sample_rate"):
+                raise TypeError("unknown rx setting %r" % k)
+            setattr(cfg, k, int(v))
+        check(self.ctx.lib.sdrhip_rx_reconfigure(self.h, C.byref(cfg)))
+        self.cfg, self.nb_fec = cfg, cfg.nb_fec
+
+    def configure(self, m):
+        """The control-message keys of sdrdaemonrx (parsekv pairs): decim, fcpos (Downsampler.cpp:32-67),
+        fecblk (UDPSink::setNbBlocksFEC), freq in Hz (setCenterFrequency: kHz on the wire), srate
+        (sample rate of the device: the sink gets srate >> decim, sdrdaemonrx.cpp:622-631).  Returns False
+        on an invalid value, like Downsampler::configure; unknown keys belong to other components."""
+        kw = {}
+        try:
+            if "decim" in m:
+                kw["log2decim"] = int(m["decim"])
+            if "fcpos" in m:
+                kw["fcpos"] = int(m["fcpos"])
+            if "fecblk" in m:
+                kw["nb_fec"] = int(m["fecblk"])
+            if "freq" in m:
+                kw["center_frequency_khz"] = int(m["freq"]) // 1000
+            if "srate" in m:
+                kw["sample_rate"] = int(m["srate"]) >> kw.get("log2decim", self.cfg.log2decim)
+            if kw:
+                self.reconfigure(**kw)
+        except (ValueError, SdrHipError) as e:
+            self.m_error = str(e)
+            return False
+        return True
 
     def max_frames(self, n_in):
         return self.ctx.lib.sdrhip_rx_max_frames(self.h, n_in)

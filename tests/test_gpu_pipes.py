@@ -226,3 +226,46 @@ def test_rx_pipe_window_wraps_and_grows(ctx, oracle):
                 assert np.array_equal(got[s, f, 128:], oracle.frame_encode(e[f], R)), (i, s, f)
         nframes += got.shape[1]
     assert nframes == sum(sizes) // per_frame
+
+
+def test_rx_pipe_live_reconfiguration(ctx, oracle):
+    """Control messages between batches (sdrhip_rx_reconfigure / RxPipe.configure): fecblk, decim + fcpos, freq +
+    srate.  Filter states carry over like the reference's shared half-band instances, an open frame keeps
+    its meta block and is encoded with the fecblk in force when it completes."""
+    import sdrdaemon_amd as sd
+
+    S = 2
+    rx = sd.RxPipe(ctx, S, log2decim=4, fcpos=sd.FC_CEN, nb_fec=32, center_frequency_khz=435000, sample_rate=625000)
+    ods = [oracle.decimators(0) for _ in range(S)]
+    frs = [oracle.framer(nb_fec_blocks=32, center_frequency_khz=435000, sample_rate=625000) for _ in range(S)]
+    steps = [  # (control message, log2, fcpos, R, decimated samples of the call)
+        ({}, 4, 2, 32, 16129 + 8000),
+        ({"fecblk": "8"}, 4, 2, 8, 16129),            # completes frame 1 (started with fecblk 32) under fecblk 8
+        ({"decim": "3", "fcpos": "0"}, 3, 0, 8, 2 * 16129 + 100),
+        ({"freq": "144800000", "srate": "2000000", "fecblk": "0"}, 3, 0, 0, 16129),
+        ({"fecblk": "20", "decim": "5", "fcpos": "2"}, 5, 2, 20, 16129 + 5),
+    ]
+    assert not rx.configure({"decim": "9"}) and "decimation" in rx.error()   # rejected, nothing changes
+    assert not rx.configure({"fecblk": "200"})
+    total = 0
+    for i, (msg, log2, fcpos, R, nd) in enumerate(steps):
+        assert rx.configure(msg), rx.error()
+        for fr in frs:
+            fr.s.nb_fec_blocks = R
+            if "freq" in msg:
+                fr.s.center_frequency_khz, fr.s.sample_rate = 144800, 2000000 >> log2
+        x = np.stack([signals.noise(nd << log2, 300 + 10 * i + s) for s in range(S)])
+        got = rx.process(x, tv_sec=50 + i, tv_usec=i)
+        assert got.shape[2] == 128 + R
+        for s in range(S):
+            y, ss = ods[s].decimate(log2, fcpos, 16, x[s])
+            frs[s].s.sample_bytes, frs[s].s.sample_bits = (ss - 1) // 8 + 1, ss
+            frs[s].s.tv_sec, frs[s].s.tv_usec = 50 + i, i
+            e = frs[s].write(y)
+            assert got.shape[1] == e.shape[0], (i, s)
+            for f in range(e.shape[0]):
+                assert np.array_equal(got[s, f, :128], e[f]), (i, s, f)
+                if R:
+                    assert np.array_equal(got[s, f, 128:], oracle.frame_encode(e[f], R)), (i, s, f)
+        total += got.shape[1]
+    assert total == 6
