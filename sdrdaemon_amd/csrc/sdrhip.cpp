@@ -303,7 +303,10 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "decimate launch: %s", hipGetErrorString(e));
     d->cur ^= 1;
-    d->stage0_int16 = cen; // m_decimator2 now holds raw int16 samples (cen) or rotate-sums (inf/sup)
+    // m_decimator2's 64-entry history now holds raw int16 samples (cen) or rotate-sums (inf/sup); a centred
+    // call shorter than the history leaves older rotate-sums in it, which the packed-int16 first stage
+    // cannot represent
+    d->stage0_int16 = cen && (a.n_used >= (size_t)2 * DEC_HIST || d->stage0_int16);
     return SDRHIP_OK;
 }
 } // namespace sdrhip
@@ -332,7 +335,8 @@ extern "C" int sdrhip_decimate(sdrhip_decimators *d, int log2decim, int fcpos, u
 
     // host buffers: stage through device memory with padded (16-byte aligned) per-stream strides
     const size_t dis = (n_in + 3) & ~(size_t)3, dos = (n_res + 3) & ~(size_t)3;
-    if (n_in == 0) { if (n_out) *n_out = 0; return SDRHIP_OK; }
+    if (n_in == 0) // nothing to stage; sampleSize still advances like in the device path
+        return decimate_device(d, log2decim, fcpos, sampleSize, nullptr, 0, 0, nullptr, 0, n_out, 0, 0, 0);
     int rc;
     if ((rc = c->in.reserve((size_t)S * dis * 4 + 16))) return rc;
     if ((rc = c->out.reserve((size_t)S * dos * 4 + 16))) return rc;

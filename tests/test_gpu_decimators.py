@@ -144,3 +144,25 @@ def test_full_size_linearity_property(ctx):
     b, _ = d2.decimate(4, 2, 16, x[cut:].contiguous())
     ctx.synchronize()
     assert torch.equal(whole, torch.cat([a, b]))
+
+
+def test_short_centred_call_after_inf_keeps_wide_history(ctx, oracle):
+    """Found by tools/fuzz_gpu.py: decimate8_sup (stage 0 sees rotate-sums > 16 bits), then a centred call
+    shorter than the 64-sample history, then a centred call: the first stage must not assume int16 history."""
+    import sdrdaemon_amd as sd
+
+    d, od = sd.Decimators(ctx, 1, 1), oracle.decimators(1)
+    for L, fc, n, seed in ((3, 1, 12289, 1), (2, 2, 40, 2), (1, 2, 6146, 3), (4, 0, 4096, 4), (4, 2, 16, 5), (4, 2, 48, 6), (4, 2, 70000, 7)):
+        x = signals.noise(n, seed)
+        y, ss = d.decimate(L, fc, 16, x)
+        e, es = od.decimate(L, fc, 16, x)
+        assert ss == es and np.array_equal(y, e), (L, fc, n)
+
+
+def test_empty_call_advances_sample_size_like_the_oracle(ctx, oracle):
+    import sdrdaemon_amd as sd
+
+    d, od = sd.Decimators(ctx, 1, 0), oracle.decimators(0)
+    x = np.zeros((0, 2), np.int16)
+    for L, fc, bits in ((2, 1, 12), (4, 2, 16), (0, 2, 8), (6, 0, 8)):
+        assert d.decimate(L, fc, bits, x)[1] == od.decimate(L, fc, bits, x)[1]

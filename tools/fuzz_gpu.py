@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Randomised parity hunt on the GPU box (not part of the test suite): random configurations and ragged
+call sequences through the C ABI against the oracle.  usage: python tools/fuzz_gpu.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import sdrdaemon_amd as sd  # noqa: E402
+import signals  # noqa: E402
+from oracle_lib import Oracle  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+orc = Oracle()
+ctx = sd.Context(0)
+t0 = time.time()
+stats = {"decim": 0, "interp": 0, "rx": 0, "tx": 0}
+
+
+def sizes(rs, scale, k):
+    out = []
+    for _ in range(k):
+        c = rs.randint(0, 6)
+        if c == 0:
+            out.append(int(rs.randint(0, 5)))
+        elif c == 1:
+            out.append(int(rs.randint(1, 300)))
+        elif c == 2:
+            out.append(int(scale * rs.randint(1, 9) + rs.randint(0, 4)))
+        else:
+            out.append(int(rs.randint(1, 40000) * (1 + 7 * (c == 5))))
+    return out
+
+
+it = 0
+while time.time() - t0 < budget:
+    it += 1
+    rs = np.random.RandomState(seed0 * 100003 + it)
+    what = rs.choice(["decim", "interp", "rx", "tx"], p=[0.4, 0.25, 0.25, 0.1])
+    if what == "decim":
+        S = int(rs.randint(1, 4))
+        bias = int(rs.randint(0, 2))
+        bits = int(rs.choice([8, 12, 16]))
+        d = sd.Decimators(ctx, S, bias)
+        ods = [orc.decimators(bias) for _ in range(S)]
+        for n in sizes(rs, 2048, int(rs.randint(1, 6))):
+            L = int(rs.randint(0, 7))
+            fc = int(rs.randint(0, 3))
+            x = np.stack([signals.noise(n, int(rs.randint(1 << 30)), bits) if rs.rand() < 0.6 else signals.mixed(n, int(rs.randint(1 << 30))) >> (16 - bits)
+                          for _ in range(S)]).astype(np.int16) if n else np.zeros((S, 0, 2), np.int16)
+            y, ss = d.decimate(L, fc, bits, x)
+            y = np.asarray(y).reshape(S, -1, 2)
+            for s in range(S):
+                e, es = ods[s].decimate(L, fc, bits, x[s])
+                assert es == ss and np.array_equal(y[s], e), ("decim", it, L, fc, bias, bits, n, s)
+    elif what == "interp":
+        S = int(rs.randint(1, 4))
+        u = sd.Interpolators(ctx, S)
+        ous = [orc.interpolators() for _ in range(S)]
+        for n in sizes(rs, 512, int(rs.randint(1, 5))):
+            L = int(rs.randint(0, 7))
+            n = min(n, 60000)
+            x = np.stack([signals.noise(n, int(rs.randint(1 << 30))) for _ in range(S)]) if n else np.zeros((S, 0, 2), np.int16)
+            y = np.asarray(u.interpolate(L, x)).reshape(S, -1, 2)
+            for s in range(S):
+                assert np.array_equal(y[s], ous[s].interpolate(L, x[s])), ("interp", it, L, n, s)
+    elif what == "rx":
+        S = int(rs.randint(1, 3))
+        L = int(rs.randint(1, 5))
+        fc = 2 if L <= 2 else int(rs.randint(0, 3))
+        R = int(rs.choice([0, 1, 7, 13, 32, 100]))
+        bias = int(rs.randint(0, 2))
+        rx = sd.RxPipe(ctx, S, log2decim=L, fcpos=fc, hb_variant=bias, nb_fec=R)
+        ods = [orc.decimators(bias) for _ in range(S)]
+        frs = [orc.framer(nb_fec_blocks=R) for _ in range(S)]
+        for k in range(int(rs.randint(1, 6))):
+            nd = int(rs.choice([3, 500, 16129, 16130, 8000, 40000, 70000]))
+            x = np.stack([signals.noise(nd << L, int(rs.randint(1 << 30))) for _ in range(S)])
+            got = rx.process(x, tv_sec=k, tv_usec=it).reshape(S, -1, 128 + R, 512)
+            for s in range(S):
+                y, ss = ods[s].decimate(L, fc, 16, x[s])
+                frs[s].s.sample_bytes, frs[s].s.sample_bits = (ss - 1) // 8 + 1, ss
+                frs[s].s.tv_sec, frs[s].s.tv_usec = k, it
+                e = frs[s].write(y)
+                assert got.shape[1] == e.shape[0], ("rx count", it, k, s)
+                for f in range(e.shape[0]):
+                    assert np.array_equal(got[s, f, :128], e[f]), ("rx frame", it, k, s, f)
+                    if R:
+                        assert np.array_equal(got[s, f, 128:], orc.frame_encode(e[f], R)), ("rx fec", it, k, s, f)
+    else:
+        F = int(rs.randint(1, 4))
+        R = int(rs.choice([8, 32, 64]))
+        L = int(rs.randint(0, 7))
+        x = signals.noise(F * 16129, int(rs.randint(1 << 30)))
+        frames = orc.framer(nb_fec_blocks=R).write(x)
+        rxb = np.zeros((F, 128, 512), np.uint8)
+        for f in range(F):
+            allb = np.concatenate([frames[f], orc.frame_encode(frames[f], R)])
+            nlost = int(rs.randint(0, R + 1))
+            lost = set(rs.choice(128 + R, nlost, replace=False).tolist())
+            if sum(1 for i in lost if i < 128) == 1:
+                lost.discard(128)  # cm256's RecoveryCount == 1 shortcut only works with recovery row 128 (mirrored quirk, tested elsewhere)
+            keep = [i for i in range(128 + R) if i not in lost][:128]
+            rxb[f] = allb[keep]
+        tx = sd.TxPipe(ctx, 1, L)
+        y = np.asarray(tx.process(rxb)).reshape(-1, 2)
+        assert np.array_equal(y, orc.interpolators().interpolate(L, x)), ("tx", it, F, R, L)
+    stats[what] += 1
+print("fuzz OK: %d iterations in %.0f s: %s" % (it, time.time() - t0, stats))
