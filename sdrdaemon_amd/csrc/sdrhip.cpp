@@ -318,7 +318,7 @@ extern "C" int sdrhip_decimate(sdrhip_decimators *d, int log2decim, int fcpos, u
     if (log2decim < 0 || log2decim > 6) return fail(SDRHIP_EINVAL, "Invalid log2 decimation factor"); // Downsampler.cpp:39-43
     if (fcpos < SDRHIP_FC_INF || fcpos > SDRHIP_FC_CEN) return fail(SDRHIP_EINVAL, "Invalid Fc position index"); // :55-59
     if (*sampleSize < 1 || *sampleSize > 16) return fail(SDRHIP_EINVAL, "sampleSize must be 1..16");
-    if (n_in && (!iq_in || !iq_out)) return fail(SDRHIP_EINVAL, "decimate: NULL buffer");
+    if (n_in && (!iq_in || (!iq_out && (n_in >> log2decim)))) return fail(SDRHIP_EINVAL, "decimate: NULL buffer"); // (no output, no buffer needed)
     sdrhip_ctx *c = d->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const int S = d->nstreams;

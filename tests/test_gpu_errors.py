@@ -103,3 +103,15 @@ def test_context_outlives_its_handles_in_any_destruction_order():
     assert y.shape == (2, 4, 2)
     for obj in (rx, u, d):
         obj.close()
+
+
+def test_device_call_too_short_for_any_output_needs_no_output_buffer(ctx):
+    """3 samples through decimate16 on device memory: torch hands out a NULL pointer for the empty result."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    d = sd.Decimators(ctx, 2, 0)
+    x = torch.zeros((2, 4, 2), dtype=torch.int16, device="cuda")
+    y, ss = d.decimate(4, 2, 16, x[:, :3])
+    assert tuple(y.shape) == (2, 0, 2) and ss == 16

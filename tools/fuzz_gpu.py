@@ -34,6 +34,8 @@ def sizes(rs, scale, k):
             out.append(int(scale * rs.randint(1, 9) + rs.randint(0, 4)))
         else:
             out.append(int(rs.randint(1, 40000) * (1 + 7 * (c == 5))))
+        if rs.rand() < 0.02:
+            out[-1] = int(rs.randint(300000, 2500000))  # many segments
     return out
 
 
@@ -53,7 +55,17 @@ while time.time() - t0 < budget:
             fc = int(rs.randint(0, 3))
             x = np.stack([signals.noise(n, int(rs.randint(1 << 30)), bits) if rs.rand() < 0.6 else signals.mixed(n, int(rs.randint(1 << 30))) >> (16 - bits)
                           for _ in range(S)]).astype(np.int16) if n else np.zeros((S, 0, 2), np.int16)
-            y, ss = d.decimate(L, fc, bits, x)
+            if n and rs.rand() < 0.4:  # device-memory path: rows padded to a multiple of 4 samples
+                import torch
+
+                pad = (n + 3) & ~3
+                xt = torch.zeros((S, pad, 2), dtype=torch.int16, device="cuda")
+                xt[:, :n] = torch.from_numpy(x).cuda()
+                yt, ss = d.decimate(L, fc, bits, xt[:, :n])
+                ctx.synchronize()
+                y = yt.cpu().numpy()
+            else:
+                y, ss = d.decimate(L, fc, bits, x)
             y = np.asarray(y).reshape(S, -1, 2)
             for s in range(S):
                 e, es = ods[s].decimate(L, fc, bits, x[s])
@@ -66,7 +78,17 @@ while time.time() - t0 < budget:
             L = int(rs.randint(0, 7))
             n = min(n, 60000)
             x = np.stack([signals.noise(n, int(rs.randint(1 << 30))) for _ in range(S)]) if n else np.zeros((S, 0, 2), np.int16)
-            y = np.asarray(u.interpolate(L, x)).reshape(S, -1, 2)
+            if n and rs.rand() < 0.4:
+                import torch
+
+                pad = (n + 3) & ~3
+                xt = torch.zeros((S, pad, 2), dtype=torch.int16, device="cuda")
+                xt[:, :n] = torch.from_numpy(x).cuda()
+                yt = u.interpolate(L, xt[:, :n])
+                ctx.synchronize()
+                y = yt.cpu().numpy().reshape(S, -1, 2)
+            else:
+                y = np.asarray(u.interpolate(L, x)).reshape(S, -1, 2)
             for s in range(S):
                 assert np.array_equal(y[s], ous[s].interpolate(L, x[s])), ("interp", it, L, n, s)
     elif what == "rx":
@@ -79,9 +101,24 @@ while time.time() - t0 < budget:
         ods = [orc.decimators(bias) for _ in range(S)]
         frs = [orc.framer(nb_fec_blocks=R) for _ in range(S)]
         for k in range(int(rs.randint(1, 6))):
+            if k and rs.rand() < 0.3:  # control message between batches
+                L = int(rs.randint(1, 5))
+                fc = 2 if L <= 2 else int(rs.randint(0, 3))
+                R = int(rs.choice([0, 1, 7, 13, 32, 100]))
+                assert rx.configure({"decim": L, "fcpos": fc, "fecblk": R}), rx.error()
+                for fr in frs:
+                    fr.s.nb_fec_blocks = R
             nd = int(rs.choice([3, 500, 16129, 16130, 8000, 40000, 70000]))
             x = np.stack([signals.noise(nd << L, int(rs.randint(1 << 30))) for _ in range(S)])
-            got = rx.process(x, tv_sec=k, tv_usec=it).reshape(S, -1, 128 + R, 512)
+            if rs.rand() < 0.3:
+                import torch
+
+                n_raw = x.shape[1]
+                xt = torch.zeros((S, (n_raw + 3) & ~3, 2), dtype=torch.int16, device="cuda")
+                xt[:, :n_raw] = torch.from_numpy(x).cuda()
+                got = rx.process_view(xt[:, :n_raw], tv_sec=k, tv_usec=it).torch().cpu().numpy().reshape(S, -1, 128 + R, 512)
+            else:
+                got = rx.process(x, tv_sec=k, tv_usec=it).reshape(S, -1, 128 + R, 512)
             for s in range(S):
                 y, ss = ods[s].decimate(L, fc, 16, x[s])
                 frs[s].s.sample_bytes, frs[s].s.sample_bits = (ss - 1) // 8 + 1, ss
