@@ -57,8 +57,9 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
     return SDRHIP_OK;
 }
 
-int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
-                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out)
+// one batch with at most DEC_SLOTS distinct erasure patterns (fec_decode_device below splits longer ones)
+static int fec_decode_chunk(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
+                            uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out)
 {
     if (nframes == 0) return SDRHIP_OK;
     const int K = SDRHIP_NB_ORIGINAL;
@@ -120,8 +121,7 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
                     if (jt->second >= 0 && !busy[jt->second]) { c->dec_free.push_back(jt->second); jt = c->dec_slot_of.erase(jt); }
                     else ++jt;
                 }
-                if (c->dec_free.empty())
-                    return fail(SDRHIP_EINVAL, "fec_decode: more than %d distinct erasure patterns in one batch; split the batch", SLOTS);
+                if (c->dec_free.empty()) return fail(SDRHIP_EINVAL, "internal: decode batch not split at %d erasure patterns", SLOTS);
                 slot = c->dec_free.back();
                 c->dec_free.pop_back();
             }
@@ -210,6 +210,36 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
         a.row_dst = c->dec_dst + (size_t)SLOTS * K;
         e = launch_gf_apply(a, c->stream);
         if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec decode launch: %s", hipGetErrorString(e));
+    }
+    return SDRHIP_OK;
+}
+
+int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
+                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out)
+{
+    // The plan cache holds DEC_SLOTS matrices: a batch with more distinct erasure patterns than that goes
+    // through in consecutive chunks (stream order keeps a slot's matrix alive until the chunk that used it
+    // has run).  The common case -- a handful of loss patterns per batch -- is one chunk.
+    const int K = SDRHIP_NB_ORIGINAL;
+    size_t f0 = 0;
+    while (f0 < nframes) {
+        std::map<std::string, char> seen;
+        size_t f1 = f0;
+        for (; f1 < nframes; ++f1) {
+            const uint8_t *idx = indices + f1 * K;
+            bool uses_recovery = false;
+            for (int p = 0; p < K && !uses_recovery; ++p) uses_recovery = idx[p] >= K;
+            if (!uses_recovery) continue;
+            std::string key(reinterpret_cast<const char *>(idx), K);
+            if (seen.count(key)) continue;
+            if ((int)seen.size() == sdrhip_ctx::DEC_SLOTS) break;
+            seen[key] = 1;
+        }
+        const int rc = fec_decode_chunk(c, rx + f0 * rx_frame_bytes, rx_frame_bytes, indices + f0 * K, f1 - f0,
+                                        payload_out + f0 * payload_frame_bytes, payload_frame_bytes,
+                                        block0_out ? block0_out + f0 * (size_t)SDRHIP_BLOCK_BYTES : nullptr);
+        if (rc) return rc;
+        f0 = f1;
     }
     return SDRHIP_OK;
 }

@@ -158,6 +158,29 @@ def test_decode_plan_cache_many_patterns(ctx, oracle):
             assert np.array_equal(b0[f], frames[f, 0, 4:]), (call, f)
 
 
+def test_decode_batch_with_more_patterns_than_cache_slots(ctx, oracle):
+    """150 frames, every one with its own erasure pattern, in ONE call: the batch goes through the 64-slot
+    plan cache in chunks."""
+    import sdrdaemon_amd as sd
+
+    R, F = 32, 150
+    rs = np.random.RandomState(77)
+    x = signals.noise(F * 16129, 56)
+    frames = oracle.framer(nb_fec_blocks=R).write(x)
+    rx = np.zeros((F, 128, 512), np.uint8)
+    for f in range(F):
+        lost = set(rs.choice(160, int(rs.randint(2, 33)), replace=False).tolist())
+        if sum(1 for i in lost if i < 128) == 1:
+            lost.discard(128)  # one lost original + lost row 128 = cm256's RecoveryCount == 1 shortcut quirk (test "m1_quirk")
+        allb = np.concatenate([frames[f], oracle.frame_encode(frames[f], R)])
+        rx[f] = allb[[i for i in range(160) if i not in lost][:128]]
+    assert len({rx[f, :, 2].tobytes() for f in range(F)}) > 2 * 64
+    payload, b0 = sd.fec_decode_frames(ctx, rx, want_block0=True)
+    for f in range(F):
+        assert np.array_equal(payload[f].view(np.int16).reshape(-1, 2), x[f * 16129:(f + 1) * 16129]), f
+        assert np.array_equal(b0[f], frames[f, 0, 4:]), f
+
+
 @pytest.mark.parametrize("R", [1, 12, 13, 16, 17, 31, 32, 33, 64, 127, 128])
 def test_frame_encoder_every_row_count(ctx, oracle, R):
     """nb_fec below 13 uses the generic kernel, from 13 on the structured (Karatsuba over the

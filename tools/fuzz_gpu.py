@@ -19,7 +19,8 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 orc = Oracle()
 ctx = sd.Context(0)
 t0 = time.time()
-stats = {"decim": 0, "interp": 0, "rx": 0, "tx": 0}
+stats = {"decim": 0, "interp": 0, "rx": 0, "tx": 0, "fec": 0}
+cm = sd.CM256(ctx)
 
 
 def sizes(rs, scale, k):
@@ -43,7 +44,7 @@ it = 0
 while time.time() - t0 < budget:
     it += 1
     rs = np.random.RandomState(seed0 * 100003 + it)
-    what = rs.choice(["decim", "interp", "rx", "tx"], p=[0.4, 0.25, 0.25, 0.1])
+    what = rs.choice(["decim", "interp", "rx", "tx", "fec"], p=[0.3, 0.2, 0.2, 0.1, 0.2])
     if what == "decim":
         S = int(rs.randint(1, 4))
         bias = int(rs.randint(0, 2))
@@ -129,8 +130,33 @@ while time.time() - t0 < budget:
                     assert np.array_equal(got[s, f, :128], e[f]), ("rx frame", it, k, s, f)
                     if R:
                         assert np.array_equal(got[s, f, 128:], orc.frame_encode(e[f], R)), ("rx fec", it, k, s, f)
+    elif what == "fec":
+        # generic CM256 geometry through the single-call ABI: encode, lose blocks, decode in place
+        k = int(rs.randint(1, 201))
+        m = int(rs.randint(1, min(256 - k, 64) + 1))
+        bb = int(rs.choice([1, 3, 4, 16, 127, 508, 509, 700, int(rs.randint(1, 2000))]))
+        orig = rs.randint(0, 256, (k, bb)).astype(np.uint8)
+        rc, rec = cm.cm256_encode((k, m, bb), orig)
+        assert rc == 0 and np.array_equal(rec, orc.cm256_encode(orig, m)), ("fec encode", it, k, m, bb)
+        nlost = int(rs.randint(0, min(k, m) + 1))
+        lost = sorted(rs.choice(k, nlost, replace=False).tolist())
+        recs = sorted(rs.choice(m, nlost, replace=False).tolist())  # recovery rows that replace them, at the lost positions
+        data = orig.copy()
+        idx = np.arange(k)
+        for p_, r_ in zip(lost, recs):
+            data[p_] = rec[r_]
+            idx[p_] = k + r_
+        if rs.rand() < 0.5:  # arrival order is arbitrary
+            perm = rs.permutation(k)
+            data, idx = np.ascontiguousarray(data[perm]), idx[perm]
+        d1, d2 = data.copy(), data.copy()
+        rc1, i1 = cm.cm256_decode((k, m, bb), d1, idx)
+        rc2, i2 = orc.cm256_decode(d2, idx, k, m)
+        assert rc1 == rc2 and np.array_equal(i1, i2) and np.array_equal(d1, d2), ("fec decode", it, k, m, bb, nlost)
+        if rc1 == 0 and not (m == 1 and nlost):  # (m == 1: the library's XOR shortcut assumes row k)
+            assert np.array_equal(d1[np.argsort(i1)], orig), ("fec roundtrip", it, k, m, bb, nlost)
     else:
-        F = int(rs.randint(1, 4))
+        F = int(rs.randint(1, 4)) if rs.rand() < 0.95 else int(rs.randint(70, 160))  # > 64 distinct patterns: plan-cache recycling
         R = int(rs.choice([8, 32, 64]))
         L = int(rs.randint(0, 7))
         x = signals.noise(F * 16129, int(rs.randint(1 << 30)))
