@@ -127,6 +127,40 @@ def cpu_baseline(budget_s):
     }
 
 
+def cpu_all_cores(budget_s):
+    """the reference decimator with one independent stream per hardware thread
+    (the reference itself runs one decimator thread per process).  Decimation leg only -- it is 95 % of the
+    CPU pipe's time; reported next to cpu_baseline, never used as the denominator of anything."""
+    import concurrent.futures as cf
+
+    import signals
+    from oracle_lib import Reference
+
+    if not Reference.available("eo1"):
+        return None
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ref = Reference("eo1")
+    n = 1 << 20
+    xs = [signals.noise(n, 5000 + t) for t in range(ncpu)]
+    decs = [ref.decimators() for _ in range(ncpu)]
+    reps = 8
+
+    def work(t):
+        k = 0
+        t_end = time.perf_counter() + budget_s
+        while time.perf_counter() < t_end:
+            decs[t].decimate_repeat(4, 2, 16, xs[t], reps)  # ctypes releases the GIL for the call
+            k += reps
+        return k
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(ncpu) as ex:
+        total = sum(ex.map(work, range(ncpu)))
+    dt = time.perf_counter() - t0
+    return {"value": round(total * n / dt / 1e6, 1), "unit": "Msamples/s", "cores": ncpu, "kind": "reference",
+            "sample": "%d threads x reference decimate16_cen on 2^20-sample blocks for %.1f s (decimation leg only)" % (ncpu, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +278,9 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             res["gpu_over_cpu_1core"] = round(value / res["cpu_baseline"]["value"], 1)
+            allc = cpu_all_cores(min(4.0, args.cpu_seconds / 3.0))
+            if allc:
+                res["cpu_baseline_all_cores"] = allc
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -22,8 +22,9 @@ namespace sdrhip {
 namespace {
 
 constexpr int GF_NT = 256;
-constexpr int RB = 4;                 // rows accumulated per wave
-constexpr int ROWS_PER_WG = 4 * RB;   // 4 waves
+// rows accumulated per wave: RB = 4, 6 or 8, a workgroup (4 waves) = 4 x RB rows of the same frames.  The
+// launch picks the smallest tile that covers the matrix in one workgroup row (24 erasures -> RB = 6): the
+// column slabs are then read and split into selectors once instead of once per 16 rows.
 static_assert(GF_FRAMES_PER_GROUP == 2, "lane mapping below assumes one frame per half-wave");
 
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
@@ -66,8 +67,9 @@ __device__ __forceinline__ void store_slab(uint8_t *p, int l, const uint4_t &v)
     if (l < 31) q[3] = v.w;
 }
 
-__global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArgs a)
+template <int RB> __global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArgs a)
 {
+    constexpr int ROWS_PER_WG = 4 * RB;
     __shared__ __attribute__((aligned(16))) unsigned tab[256 * 8];              // 8 KB
     __shared__ __attribute__((aligned(16))) uint8_t coef[ROWS_PER_WG * 256];    // rows x cols (cols <= 256)
 
@@ -180,39 +182,47 @@ constexpr int KLEAVES = 81;                                                     
 __host__ __device__ constexpr int pow3(int n) { return n <= 1 ? 1 : 3 * pow3(n / 2); }    // leaves of an n-point node
 __host__ __device__ constexpr int sbase(int n) { return KN + (KN - n); }                  // scratch of the level of size n
 
-// y[YO .. YO+N) ^= g (*) v[ZO .. ZO+N); lt16 / lt4 = LDS byte addresses of the leaf tables of the block
+// ya[YO .. YO+N) ^= ga (*) v[ZO .. ZO+N) and yb[..] ^= gb (*) v[..] in one walk of the Karatsuba tree: the two
+// kernel blocks (the two 16-row tiles of a row pair) see the same z sums, so the tree's XORs on the z side
+// and the three selector words of every leaf are formed once and used twice.  la16 / la4, lb16 / lb4 = LDS
+// byte addresses of the leaf tables of the two blocks.
 template <int N, int ZO, int YO, int LEAF0>
-__device__ __forceinline__ void acc_conv(unsigned (&v)[2 * KN - 1], unsigned (&y)[KN], unsigned lt16, unsigned lt4)
+__device__ __forceinline__ void acc_conv2(unsigned (&v)[2 * KN - 1], unsigned (&ya)[KN], unsigned (&yb)[KN], unsigned la16, unsigned la4,
+                                          unsigned lb16, unsigned lb4)
 {
     if constexpr (N == 1) {
         // The 81 table loads of a block have immediate addresses; left to the compiler they are all
-        // hoisted to the top (405 VGPRs of tables) and spilled.  An asm statement that loads one leaf's
-        // tables and waits for them keeps them in program order; the other waves of the SIMD cover the
-        // LDS latency (4-6 resident waves, 11 lane-ops per leaf each).
-        uint4_t t;
-        unsigned tc;
+        // hoisted to the top (hundreds of VGPRs of tables) and spilled.  An asm statement that loads one
+        // leaf's tables and waits for them keeps them in program order; the other waves of the SIMD cover
+        // the LDS latency.
+        uint4_t ta, tb;
+        unsigned tca, tcb;
         unsigned z = v[ZO]; // tied to the statement ("+v") so that its three selector dwords are formed here,
                             // not when v[ZO] is produced (that alone tripled the live registers)
-        asm volatile("ds_read_b128 %0, %3 offset:%c5\n\tds_read_b32 %1, %4 offset:%c6\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(t), "=&v"(tc), "+v"(z)
-                     : "v"(lt16), "v"(lt4), "i"(LEAF0 * 16), "i"(LEAF0 * 4)
+        asm volatile("ds_read_b128 %0, %5 offset:%c9\n\tds_read_b32 %1, %6 offset:%c10\n\t"
+                     "ds_read_b128 %2, %7 offset:%c9\n\tds_read_b32 %3, %8 offset:%c10\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(ta), "=&v"(tca), "=&v"(tb), "=&v"(tcb), "+v"(z)
+                     : "v"(la16), "v"(la4), "v"(lb16), "v"(lb4), "i"(LEAF0 * 16), "i"(LEAF0 * 4)
                      : "memory");
-        y[YO] ^= kmul(z, t, tc);
+        const unsigned sa = z & 0x07070707u, sb = (z >> 3) & 0x07070707u, sc = (z >> 6) & 0x03030303u;
+        ya[YO] ^= __builtin_amdgcn_perm(ta.y, ta.x, sa) ^ __builtin_amdgcn_perm(ta.w, ta.z, sb) ^ __builtin_amdgcn_perm(0u, tca, sc);
+        yb[YO] ^= __builtin_amdgcn_perm(tb.y, tb.x, sa) ^ __builtin_amdgcn_perm(tb.w, tb.z, sb) ^ __builtin_amdgcn_perm(0u, tcb, sc);
+        asm volatile("" : "+v"(ya[YO]), "+v"(yb[YO])); // accumulate now: the compiler otherwise parks the six products of many leaves
     } else {
         constexpr int H = N / 2, L3 = pow3(H);
 #pragma unroll
-        for (int i = 0; i < H; ++i) y[YO + H + i] ^= y[YO + i];
-        acc_conv<H, ZO, YO, LEAF0>(v, y, lt16, lt4);
-        acc_conv<H, ZO + H, YO, LEAF0 + L3>(v, y, lt16, lt4);
+        for (int i = 0; i < H; ++i) { ya[YO + H + i] ^= ya[YO + i]; yb[YO + H + i] ^= yb[YO + i]; }
+        acc_conv2<H, ZO, YO, LEAF0>(v, ya, yb, la16, la4, lb16, lb4);
+        acc_conv2<H, ZO + H, YO, LEAF0 + L3>(v, ya, yb, la16, la4, lb16, lb4);
 #pragma unroll
         for (int i = 0; i < H; ++i) v[sbase(N) + i] = v[ZO + i] ^ v[ZO + H + i];
-        acc_conv<H, sbase(N), YO + H, LEAF0 + 2 * L3>(v, y, lt16, lt4);
+        acc_conv2<H, sbase(N), YO + H, LEAF0 + 2 * L3>(v, ya, yb, la16, la4, lb16, lb4);
 #pragma unroll
-        for (int i = 0; i < H; ++i) y[YO + H + i] ^= y[YO + i];
+        for (int i = 0; i < H; ++i) { ya[YO + H + i] ^= ya[YO + i]; yb[YO + H + i] ^= yb[YO + i]; }
     }
 }
 
-__global__ __launch_bounds__(GF_NT, 3) void gf_encode128_kernel(Enc128Args a)
+__global__ __launch_bounds__(GF_NT, 4) void gf_encode128_kernel(Enc128Args a) // 105 VGPRs: 4 waves per SIMD
 {
     __shared__ __attribute__((aligned(16))) uint4_t lt16[8 * KLEAVES];  // {Ta, Tb} of the leaves of G_0..G_7
     __shared__ unsigned lt4[8 * KLEAVES];                                // {Tc}
@@ -264,8 +274,8 @@ __global__ __launch_bounds__(GF_NT, 3) void gf_encode128_kernel(Enc128Args a)
 #pragma unroll
             for (int i = 0; i < KN; ++i) p ^= v[i];
             const int b0 = (2 * tp) ^ cb, b1 = (2 * tp + 1) ^ cb;
-            acc_conv<KN, 0, 0, 0>(v, y0, lds_addr(lt16 + b0 * KLEAVES), lds_addr(lt4 + b0 * KLEAVES));
-            acc_conv<KN, 0, 0, 0>(v, y1, lds_addr(lt16 + b1 * KLEAVES), lds_addr(lt4 + b1 * KLEAVES));
+            acc_conv2<KN, 0, 0, 0>(v, y0, y1, lds_addr(lt16 + b0 * KLEAVES), lds_addr(lt4 + b0 * KLEAVES),
+                                   lds_addr(lt16 + b1 * KLEAVES), lds_addr(lt4 + b1 * KLEAVES));
         }
         if (tp == 0) __hip_atomic_fetch_xor(&ysum[32][lane], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
@@ -330,8 +340,13 @@ hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream)
     if (a.nframes <= 0 || a.rows <= 0) return hipSuccess;
     const int ngroups = a.frame_list ? a.ngroups : (a.nframes + GF_FRAMES_PER_GROUP - 1) / GF_FRAMES_PER_GROUP;
     if (ngroups <= 0) return hipSuccess;
-    dim3 grid(ngroups, (a.rows + ROWS_PER_WG - 1) / ROWS_PER_WG);
-    hipLaunchKernelGGL(gf_apply_kernel, grid, dim3(GF_NT), 0, stream, a);
+    if (a.rows <= 16) {
+        hipLaunchKernelGGL(gf_apply_kernel<4>, dim3(ngroups, 1), dim3(GF_NT), 0, stream, a);
+    } else if (a.rows <= 24) {
+        hipLaunchKernelGGL(gf_apply_kernel<6>, dim3(ngroups, 1), dim3(GF_NT), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(gf_apply_kernel<8>, dim3(ngroups, (a.rows + 31) / 32), dim3(GF_NT), 0, stream, a);
+    }
     return hipGetLastError();
 }
 
