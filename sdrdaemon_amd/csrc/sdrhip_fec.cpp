@@ -91,16 +91,22 @@ static int fec_decode_chunk(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_by
     std::vector<uint8_t> coef((size_t)K * K), rec_pos(K), erased(256);
     int max_rows = 0;
     bool any_b0 = false;
+    std::vector<size_t> holes; // frames that will not be written completely: their output is zeroed first
     for (size_t f = 0; f < nframes; ++f) {
         const uint8_t *idx = indices + f * K;
         int n_recovery = 0;
+        uint64_t have[2] = {0, 0};
         for (int p = 0; p < K; ++p) {
             const int b = idx[p];
             pmap[f * K + p] = (b >= 1 && b < K) ? (int16_t)(b - 1) : (int16_t)-1; // payload slot of block b
             zmap[f * K + p] = b == 0 ? (int16_t)0 : (int16_t)-1;
             if (b >= K) ++n_recovery;
+            else have[b >> 6] |= (uint64_t)1 << (b & 63);
         }
-        if (n_recovery == 0) continue;
+        if (n_recovery == 0) {
+            if (~have[0] || ~have[1]) holes.push_back(f); // 128 originals with repeats: some block never arrived
+            continue;
+        }
         std::string key(reinterpret_cast<const char *>(idx), K);
         auto it = c->dec_slot_of.find(key);
         if (it == c->dec_slot_of.end()) {
@@ -130,6 +136,7 @@ static int fec_decode_chunk(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_by
             if (cm256_decode_plan(K, n_recovery, idx, &n_rec, rec_pos.data(), erased.data(), coef.data())) {
                 c->dec_free.push_back(slot);
                 c->dec_slot_of[key] = -1; // "CM256 decode error" (:199): the frame keeps what was received
+                holes.push_back(f);
                 continue;
             }
             c->dec_nrec[slot] = n_rec;
@@ -147,7 +154,7 @@ static int fec_decode_chunk(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_by
             new_slots.push_back(slot);
         }
         const int slot = it->second;
-        if (slot < 0) continue;
+        if (slot < 0) { if (holes.empty() || holes.back() != f) holes.push_back(f); continue; }
         auto mo = member_of.find(slot);
         if (mo == member_of.end()) {
             mo = member_of.insert(std::make_pair(slot, (int)members.size())).first;
@@ -176,13 +183,24 @@ static int fec_decode_chunk(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_by
     }
     c->pin.mark(c->stream);
 
-    // ---- payload = zeros (initDecodeSlot memset, :109) + received originals in place
-    HIP_TRY(hipMemsetAsync(payload_out, 0, nframes * payload_frame_bytes, c->stream));
+    // ---- payload = zeros (initDecodeSlot memset, :109) + received originals in place.  A frame whose 127
+    // payload blocks all get written (received or recovered) needs no zero fill: only the undecodable ones do.
+    if (holes.size() > 32) {
+        HIP_TRY(hipMemsetAsync(payload_out, 0, nframes * payload_frame_bytes, c->stream));
+    } else {
+        for (size_t h = 0; h < holes.size(); ++h)
+            HIP_TRY(hipMemsetAsync(payload_out + holes[h] * payload_frame_bytes, 0, (size_t)(K - 1) * SDRHIP_BLOCK_BYTES, c->stream));
+    }
     hipError_t e = launch_block_scatter(rx, rx_frame_bytes, SDRHIP_UDPSIZE, 4, payload_out, payload_frame_bytes, SDRHIP_BLOCK_BYTES, 0,
                                         reinterpret_cast<const int16_t *>(dv + o_pmap), K, (int)nframes, c->stream);
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "scatter launch: %s", hipGetErrorString(e));
     if (block0_out) {
-        HIP_TRY(hipMemsetAsync(block0_out, 0, nframes * (size_t)SDRHIP_BLOCK_BYTES, c->stream));
+        if (holes.size() > 32) {
+            HIP_TRY(hipMemsetAsync(block0_out, 0, nframes * (size_t)SDRHIP_BLOCK_BYTES, c->stream));
+        } else {
+            for (size_t h = 0; h < holes.size(); ++h)
+                HIP_TRY(hipMemsetAsync(block0_out + holes[h] * (size_t)SDRHIP_BLOCK_BYTES, 0, SDRHIP_BLOCK_BYTES, c->stream));
+        }
         e = launch_block_scatter(rx, rx_frame_bytes, SDRHIP_UDPSIZE, 4, block0_out, SDRHIP_BLOCK_BYTES, SDRHIP_BLOCK_BYTES, 0,
                                  reinterpret_cast<const int16_t *>(dv + o_zmap), K, (int)nframes, c->stream);
         if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "scatter launch: %s", hipGetErrorString(e));

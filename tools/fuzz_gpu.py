@@ -169,6 +169,16 @@ while time.time() - t0 < budget:
             if sum(1 for i in lost if i < 128) == 1:
                 lost.discard(128)  # cm256's RecoveryCount == 1 shortcut only works with recovery row 128 (mirrored quirk, tested elsewhere)
             keep = [i for i in range(128 + R) if i not in lost][:128]
+            if rs.rand() < 0.12:
+                # a frame that never reaches 128 blocks (the reference emits it with holes, SDRdaemonFECBuffer.cpp:72-75,
+                # 109): the batched API wants 128 entries, the caller pads with a repeat -> not decodable -> zeros in the holes
+                keep = [i for i in keep if i < 128][:int(rs.randint(1, 120))]
+                hole = np.zeros((127, 508), np.uint8)
+                for b in keep:
+                    if b >= 1:
+                        hole[b - 1] = allb[b, 4:]
+                x[f * 16129:(f + 1) * 16129] = hole.reshape(-1).view(np.int16).reshape(-1, 2)
+                keep = keep + [keep[0]] * (128 - len(keep))
             rxb[f] = allb[keep]
         tx = sd.TxPipe(ctx, 1, L)
         y = np.asarray(tx.process(rxb)).reshape(-1, 2)
