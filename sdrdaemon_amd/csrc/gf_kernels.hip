@@ -152,20 +152,18 @@ template <int RB> __global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArg
 // (because (128 ^ j) ^ (128 ^ (r ^ j)) = r), hence
 //     recovery_r = P ^ r * (G (*) x)[r],   P = XOR of the 128 originals,
 // where (*) is an XOR-convolution over the block index: (G (*) x)[r] = XOR_j G[r ^ j] x_j.  Splitting
-// j = 32 jh + jl and r = 32 t + rl turns it into 32-point dyadic convolutions with the kernel blocks
-// G_b[u] = G[32 b + u], b = t ^ jh, and over a field of characteristic 2 those obey a Karatsuba rule
+// j = 16 cb + jl and r = 16 rt + rl turns it into 16-point dyadic convolutions with the kernel blocks
+// G_b[u] = G[16 b + u], b = rt ^ cb, and over a field of characteristic 2 those obey a Karatsuba rule
 //     y_lo = g_lo(*)z_lo ^ g_hi(*)z_hi,   y_hi = y_lo ^ (g_lo ^ g_hi)(*)(z_lo ^ z_hi)
-// (3 half-size products instead of 4).  Four levels on 16-point blocks: 81 constant multiplications +
-// 195 XORs per 16 x 16 block instead of 256 multiplications -- ~18 k lane-ops per 4-byte column of a
-// frame instead of 36 k for the generic kernel above.  One lane owns one 4-byte column of a frame (64
-// lanes x 2 waves = the 127 dwords of a block); the 243 leaf constants of each G_b come from the host
-// in depth-first order as ready-made 32-byte multiplier tables (immediate LDS offsets, no dependent loads).
-// Implementation: 16-point blocks (j = 16 cb + jl, r = 16 rt + rl, kernel block G_b[u] = G[16 b + u],
-// b = rt ^ cb; 81 leaves + 195 XORs per 16 x 16 block) keep the per-lane state at ~80 VGPRs.  A
-// workgroup = one (frame, half block) = 64 four-byte columns; its four waves take two column blocks
-// each, apply them to a pair of row tiles, XOR their partial sums into LDS (ds_xor), then each wave
-// finishes 8 of the 32 rows: recovery_r = P ^ r * c_r.  Leaf tables sit in LDS as {Ta, Tb} (16 B) +
-// {Tc} (4 B) arrays with immediate offsets: no dependent loads.
+// (3 half-size products instead of 4).  Four levels: 81 constant multiplications + 195 XORs per
+// 16 x 16 block instead of 256 multiplications.  The 81 leaf constants of each of the 8 blocks G_b come
+// from the host (gf256.cpp, cm256_karatsuba_leaf_tables) in depth-first order as ready-made 32-byte
+// multiplier tables and sit in LDS as {Ta, Tb} (16 B) + {Tc} (4 B) arrays: immediate offsets, no
+// dependent loads.
+// A lane owns one 4-byte column of a frame; a workgroup = one (frame, half block) = 64 columns; its four
+// waves take two column blocks each, apply them to BOTH 16-row tiles of a row pair in one walk of the
+// tree (acc_conv2), XOR their partial sums into LDS (ds_xor), then each wave finishes 8 of the 32 rows:
+// recovery_r = P ^ r * c_r, and writes their {frameIndex, 128 + r, 0} headers.
 __device__ __forceinline__ unsigned kmul(unsigned zval, const uint4_t &t, unsigned tc)
 {
     const unsigned sa = zval & 0x07070707u, sb = (zval >> 3) & 0x07070707u, sc = (zval >> 6) & 0x03030303u;

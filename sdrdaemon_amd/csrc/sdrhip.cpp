@@ -87,6 +87,10 @@ extern "C" int sdrhip_device_count(void)
     return n;
 }
 
+namespace sdrhip {
+static void ctx_free(sdrhip_ctx *c);
+}
+
 extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
 {
     if (!out) return fail(SDRHIP_EINVAL, "ctx_create: out is NULL");
@@ -101,23 +105,22 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
     c->stream = static_cast<hipStream_t>(hip_stream);
     std::vector<uint8_t> tab(256 * 32);
     gf_build_tables(tab.data());
-    if (hipMalloc(reinterpret_cast<void **>(&c->gf_tab), tab.size()) != hipSuccess) { delete c; return fail(SDRHIP_ENOMEM, "hipMalloc gf tables"); }
-    if (hipMemcpy(c->gf_tab, tab.data(), tab.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(c->gf_tab); delete c; return fail(SDRHIP_EDEVICE, "upload gf tables"); }
+    if (hipMalloc(reinterpret_cast<void **>(&c->gf_tab), tab.size()) != hipSuccess) { c->gf_tab = nullptr; ctx_free(c); return fail(SDRHIP_ENOMEM, "hipMalloc gf tables"); }
+    if (hipMemcpy(c->gf_tab, tab.data(), tab.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx_free(c); return fail(SDRHIP_EDEVICE, "upload gf tables"); }
     std::vector<uint8_t> em(128 * 128);
     cm256_encode_matrix(128, 128, em.data());
     if (hipMalloc(reinterpret_cast<void **>(&c->enc_matrix), em.size()) != hipSuccess ||
-        hipMemcpy(c->enc_matrix, em.data(), em.size(), hipMemcpyHostToDevice) != hipSuccess) { delete c; return fail(SDRHIP_ENOMEM, "upload encode matrix"); }
+        hipMemcpy(c->enc_matrix, em.data(), em.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "upload encode matrix"); }
     std::vector<uint8_t> kl(8 * 81 * 32);
     cm256_karatsuba_leaf_tables(kl.data());
     if (hipMalloc(reinterpret_cast<void **>(&c->enc_leaves), kl.size()) != hipSuccess ||
-        hipMemcpy(c->enc_leaves, kl.data(), kl.size(), hipMemcpyHostToDevice) != hipSuccess) { delete c; return fail(SDRHIP_ENOMEM, "upload encoder constants"); }
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { delete c; return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
+        hipMemcpy(c->enc_leaves, kl.data(), kl.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "upload encoder constants"); }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { ctx_free(c); return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
     *out = c;
     return SDRHIP_OK;
 }
 
 namespace sdrhip {
-static void ctx_free(sdrhip_ctx *c);
 void ctx_retain(sdrhip_ctx *c) { ++c->refs; }
 void ctx_release(sdrhip_ctx *c)
 {
@@ -138,7 +141,7 @@ static void sdrhip::ctx_free(sdrhip_ctx *c)
 {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    c->in.release(); c->out.release(); c->aux.release(); c->aux2.release(); c->aux3.release();
+    c->in.release(); c->out.release(); c->aux.release(); c->aux3.release();
     if (c->gf_tab) (void)hipFree(c->gf_tab);
     if (c->enc_matrix) (void)hipFree(c->enc_matrix);
     if (c->enc_leaves) (void)hipFree(c->enc_leaves);

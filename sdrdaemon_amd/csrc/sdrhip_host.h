@@ -67,7 +67,7 @@ struct sdrhip_ctx {
     hipStream_t stream = nullptr;
     int refs = 0;       // handles created on this context (they keep it alive)
     bool dying = false; // sdrhip_ctx_destroy was called while handles were still alive
-    sdrhip::DevBuf in, out, aux, aux2, aux3; // staging for SDRHIP_MEM_HOST calls and FEC work areas
+    sdrhip::DevBuf in, out, aux, aux3;       // staging for SDRHIP_MEM_HOST calls and FEC work areas
     uint8_t *gf_tab = nullptr;               // 256 x 32 B multiplier tables (device)
     uint8_t *enc_matrix = nullptr;           // 128 x 128 encode matrix, rows 128..255 (device)
     uint8_t *enc_leaves = nullptr;           // Karatsuba leaf tables of the structured k = 128 encoder (device)
