@@ -66,7 +66,8 @@ def pmc_traffic(samples_per_launch):
         return None
 
 
-VALU_PEAK_TLANEOPS = 1024 * 16 * 2.4e9 / 1e12  # 1024 SIMDs x 16 integer lanes / clk x 2.4 GHz
+VALU_PEAK_TLANEOPS = 1024 * 16 * 2.4e9 / 1e12  # 1024 SIMDs x 16 lanes / clk x 2.4 GHz: the issue rate of the multiplier-class ops
+# (mad / dot2 / perm, 62 % of K1's mix; plain add / xor / shift issue faster: tools/valu_peak.hip)
 
 
 def pmc_valu_lane_ops(samples_per_launch):
@@ -271,7 +272,7 @@ def main():
         }
         lane_ops = pmc_valu_lane_ops(per_launch_samples)
         if lane_ops and dec_n:
-            # the ceiling that actually binds K1 (secondary figure of SURVEY.md 8d): integer VALU issue
+            # secondary figure of SURVEY.md 8(d): integer VALU issue, every op counted at the 16-lane / clk rate
             tl = lane_ops / (avg_ms * 1e-3) / 1e12
             res["roofline"]["valu"] = {"achieved": round(tl, 2), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "T lane-ops/s",
                                        "frac": round(tl / VALU_PEAK_TLANEOPS, 4), "lane_ops_per_sample": round(lane_ops / per_launch_samples, 2)}

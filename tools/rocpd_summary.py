@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 rocpd (sqlite) outputs: per-kernel stats and per-kernel PMC averages.
 usage: rocpd_summary.py run_results.db [more.db ...]"""
+import os
 import sqlite3
 import sys
 
@@ -31,7 +32,7 @@ def main():
             print("counters_collection columns:", ccols, e)
             continue
         for n in sorted(set(r[0] for r in pm)):
-            if "decim_kernel" in n or "gf_" in n or "interp_kernel" in n:
+            if "decim_kernel" in n or "gf_" in n or "interp_kernel" in n or os.environ.get("ROCPD_ALL_KERNELS"):
                 print("  PMC", short(n), "vgpr", [r[4] for r in pm if r[0] == n][0], "lds", [r[5] for r in pm if r[0] == n][0])
                 for r in pm:
                     if r[0] == n:
