@@ -337,6 +337,21 @@ template <int L, int FC, bool PACK16> __global__ __launch_bounds__(NT) void deci
     oc.out = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
     oc.out_pos = seg_start >> L;
 
+    // fused Rx pipe: meta block + super block headers of the frames this call starts, one frame per
+    // workgroup (frame i of the stream by segment i mod nseg); nothing else writes those dwords
+    if (a.frame_mode && tid < 128) {
+        unsigned mw = 0u; // dword tid of block 0 behind the header: the 24-byte MetaDataFEC, then zeros
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (tid == k + 1) mw = a.meta_w[k];
+        for (int fi = seg; fi < a.meta_count; fi += a.nseg) {
+            unsigned *fr = oc.out + (size_t)(a.meta_first + fi) * a.frame_blocks * 128u;
+            const unsigned fidx = (a.meta_frame_count0 + (unsigned)fi) & 0xffffu;
+            fr[tid] = tid == 0 ? fidx : mw; // block 0: 512 bytes = 128 dwords
+            if (tid >= 1) fr[(size_t)tid * 128] = fidx | ((unsigned)tid << 16);
+        }
+    }
+
     int fill[6] = {0, 0, 0, 0, 0, 0};
     bool warm = (seg != 0);
     size_t pos = warm ? seg_start - WRAW : 0;

@@ -288,34 +288,4 @@ hipError_t launch_interpolate(int log2interp, const InterpArgs &a, hipStream_t s
     return hipErrorInvalidValue;
 }
 
-// ------------------------------------------------------------------------------------------
-// meta block + super block headers of the frames started by an Rx call (UDPSinkFEC.cpp:87-132,
-// 150-152): block 0 = header {frameIndex, 0, 0} + 24-byte MetaDataFEC + zero fill; blocks
-// 1..127 get {frameIndex, blockIndex, 0}.  One workgroup per (frame, stream).
-struct Meta24 { unsigned w[6]; };
-__global__ void frame_meta_kernel(uint8_t *work, size_t stream_bytes, int frame_blocks, int first_frame, unsigned frame_count0,
-                                  Meta24 meta)
-{
-    const int f = first_frame + blockIdx.x;
-    const int stream = blockIdx.y;
-    unsigned *fr = reinterpret_cast<unsigned *>(work + (size_t)stream * stream_bytes + (size_t)f * frame_blocks * 512);
-    const unsigned fidx = (frame_count0 + blockIdx.x) & 0xffffu;
-    const int t = threadIdx.x;
-    if (t < 128) {
-        fr[t] = t == 0 ? fidx : (t <= 6 ? meta.w[t - 1] : 0u); // block 0: 512 bytes = 128 dwords
-        if (t >= 1) fr[(size_t)t * 128] = fidx | ((unsigned)t << 16);
-    }
-}
-
-hipError_t launch_frame_meta(uint8_t *work, size_t stream_bytes, int frame_blocks, int nstreams, int first_frame, int nframes,
-                             unsigned frame_count0, const uint8_t *meta24_host, hipStream_t stream)
-{
-    if (nframes <= 0) return hipSuccess;
-    Meta24 m;
-    memcpy(m.w, meta24_host, 24); // travels in the kernel arguments: no upload, no staging buffer
-    hipLaunchKernelGGL(frame_meta_kernel, dim3(nframes, nstreams), dim3(128), 0, stream, work, stream_bytes, frame_blocks, first_frame,
-                       frame_count0, m);
-    return hipGetLastError();
-}
-
 } // namespace sdrhip

@@ -258,7 +258,7 @@ namespace sdrhip {
 // device-pointer core shared with the fused Rx pipe; frame_* = 0 for plain output
 int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in,
                     size_t n_in, size_t in_stride, int16_t *out, size_t out_stride, size_t *n_out, int frame_mode,
-                    int frame_blocks, uint64_t frame_sample_base)
+                    int frame_blocks, uint64_t frame_sample_base, const RxMeta *meta)
 {
     sdrhip_ctx *c = d->ctx;
     const unsigned L = (unsigned)log2decim;
@@ -296,6 +296,10 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     a.nstreams = d->nstreams;
     a.bias = d->bias; a.norm = (int)norm; a.trunk = (int)trunk;
     a.frame_mode = frame_mode; a.frame_blocks = frame_blocks; a.frame_sample_base = frame_sample_base;
+    if (meta) {
+        a.meta_first = meta->first; a.meta_count = meta->count; a.meta_frame_count0 = meta->frame_count0;
+        memcpy(a.meta_w, meta->w, sizeof(a.meta_w));
+    }
     plan_decimate((int)L, fcpos, a.n_used, d->nstreams, &a.nsub_per_seg, &a.nseg);
     const bool cen = (fcpos == SDRHIP_FC_CEN);
     const bool pack16 = cen && d->stage0_int16;

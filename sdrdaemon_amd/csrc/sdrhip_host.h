@@ -45,10 +45,25 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 void ctx_retain(sdrhip_ctx *c);
 void ctx_release(sdrhip_ctx *c);
 
+// meta blocks the decimator kernel writes for the fused Rx pipe (DecimArgs::meta_*)
+struct RxMeta {
+    int first, count;
+    unsigned frame_count0;
+    unsigned w[6]; // MetaDataFEC, 24 bytes
+};
+
+// sampleSize after decimateN (Decimators.cpp:43-44, 112-113 ...): grows by log2decim, capped at 16 bits
+inline unsigned decimated_sample_size(unsigned log2decim, unsigned ss)
+{
+    if (log2decim == 0) return ss;
+    const unsigned target = 16 - log2decim, trunk = ss < target ? 0 : ss - target;
+    return ss + log2decim - trunk;
+}
+
 // device-pointer cores (no argument validation, no staging)
 int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in, size_t n_in,
                     size_t in_stride, int16_t *out, size_t out_stride, size_t *n_out, int frame_mode, int frame_blocks,
-                    uint64_t frame_sample_base);
+                    uint64_t frame_sample_base, const RxMeta *meta = nullptr);
 int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *in, size_t n_in, size_t in_stride, int16_t *out,
                        size_t out_stride, size_t *n_out);
 // frames/recovery on the device; recovery slots may be interleaved with the frames

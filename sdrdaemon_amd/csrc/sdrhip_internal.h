@@ -40,6 +40,12 @@ struct DecimArgs {
     int frame_mode;
     int frame_blocks;        // super blocks per frame slot (128 + nb_fec)
     uint64_t frame_sample_base; // samples already sitting in the first (partial) frame slot
+    // meta blocks of the frames this call starts (UDPSinkFEC.cpp:87-132, 150-152): frame slots meta_first ..
+    // meta_first + meta_count - 1 of every stream get block 0 = {header, 24-byte MetaDataFEC, zero fill} and
+    // the {frameIndex, blockIndex, 0} headers of blocks 1..127; frameIndex = meta_frame_count0 + i (mod 2^16)
+    int meta_first, meta_count;
+    unsigned meta_frame_count0;
+    unsigned meta_w[6];
 };
 
 // returns hipSuccess or the launch error

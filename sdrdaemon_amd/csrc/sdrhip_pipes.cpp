@@ -116,11 +116,6 @@ extern "C" int sdrhip_interpolate(sdrhip_interpolators *p, int log2interp, const
 }
 
 // --------------------------------------------------------------------------- fused Rx pipe
-namespace sdrhip {
-hipError_t launch_frame_meta(uint8_t *work, size_t stream_bytes, int frame_blocks, int nstreams, int first_frame, int nframes,
-                             unsigned frame_count0, const uint8_t *meta24, hipStream_t stream);
-}
-
 struct sdrhip_rx {
     sdrhip_ctx *ctx;
     int nstreams;
@@ -287,22 +282,20 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     const size_t stream_bytes = rx->cap_frames * frame_bytes;
     uint8_t *work = rx->work.as<uint8_t>() + rx->base_slot * frame_bytes; // slot 0 of the window
 
-    // ---- decimate straight into the frame layout
+    // ---- meta record of the frames started by this call (UDPSinkFEC.cpp:87-132); the decimator kernel writes
+    // their meta blocks and super block headers on its way
     unsigned ss = rx->cfg.sample_bits;
-    size_t n_out = 0;
-    rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, reinterpret_cast<int16_t *>(work), stream_bytes / 4, &n_out, 1,
-                         FB, rx->pending_samples);
-    if (rc) return rc;
-
-    // ---- meta blocks + headers of the frames started by this call (UDPSinkFEC.cpp:87-132)
     const int first_new = rx->frame_open ? 1 : 0;
-    const int started = (int)(done + (rest > 0 ? 1 : 0)) - first_new; // frames whose first sample arrived now
+    const int started = (int)(done + (rest > 0 ? 1 : 0)) - first_new; // frames whose first sample arrives now
+    RxMeta meta;
+    memset(&meta, 0, sizeof(meta));
     if (started > 0) {
+        const unsigned ssd = decimated_sample_size((unsigned)L, ss);
         uint8_t m[24];
         const uint32_t fc = rx->cfg.center_frequency_khz, sr = rx->cfg.sample_rate;
         memcpy(m + 0, &fc, 4); memcpy(m + 4, &sr, 4);
-        m[8] = (uint8_t)((ss - 1) / 8 + 1); // setSampleBytes((sampleSize - 1) / 8 + 1), sdrdaemonrx.cpp:643
-        m[9] = (uint8_t)ss;                 // setSampleBits(sampleSize), :642
+        m[8] = (uint8_t)((ssd - 1) / 8 + 1); // setSampleBytes((sampleSize - 1) / 8 + 1), sdrdaemonrx.cpp:643
+        m[9] = (uint8_t)ssd;                 // setSampleBits(sampleSize), :642
         m[10] = SDRHIP_NB_ORIGINAL; m[11] = (uint8_t)R;
         memcpy(m + 12, &tv_sec, 4); memcpy(m + 16, &tv_usec, 4);
         // boost::crc_32_type over the first 20 bytes (UDPSinkFEC.cpp:106-109)
@@ -313,9 +306,15 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         }
         crc ^= 0xFFFFFFFFu;
         memcpy(m + 20, &crc, 4);
-        hipError_t e = launch_frame_meta(work, stream_bytes, FB, S, first_new, started, (unsigned)rx->frame_count + first_new, m, c->stream);
-        if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "frame meta launch: %s", hipGetErrorString(e));
+        meta.first = first_new; meta.count = started; meta.frame_count0 = (unsigned)rx->frame_count + first_new;
+        memcpy(meta.w, m, 24);
     }
+
+    // ---- decimate straight into the frame layout
+    size_t n_out = 0;
+    rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, reinterpret_cast<int16_t *>(work), stream_bytes / 4, &n_out, 1,
+                         FB, rx->pending_samples, &meta);
+    if (rc) return rc;
 
     // ---- FEC over the completed frames of every stream, recovery blocks land behind block 127
     if (done && R > 0) {
