@@ -68,6 +68,8 @@ __device__ __forceinline__ int dot2(unsigned a, unsigned taps, int acc)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, taps), acc, false);
 }
 
+__device__ __forceinline__ int dot2_link(unsigned a, unsigned taps, int acc) { return dot2(a, taps, acc); }
+
 // first link of a dot2 chain: the three-address form (d = a . b + c) takes the chain's initial value from a
 // VGPR that stays put; hipcc only emits the accumulate-in-place v_dot2c and a v_mov per chain in front of it
 __device__ __forceinline__ int dot2_init(unsigned a, unsigned taps, int c)
@@ -146,23 +148,28 @@ template <class G, int S> __device__ __forceinline__ void run_stage(int *lds, in
             uint4_t v = *reinterpret_cast<const uint4_t *>(pe + k0 / 2 + 8 + d);
             we[d] = v.x; we[d + 1] = v.y; we[d + 2] = v.z; we[d + 3] = v.w;
         }
+        // The R accumulation chains advance in lockstep (link t of every chain, then link t + 1): consecutive
+        // instructions of a wave are then independent.  Written chain after chain, every v_dot2c waits for
+        // the one before it, and the SIMD only stays busy while other waves happen to have VALU work.
         const int bias13 = bias << 13;
+        int acc[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            int acc;
-            if (r & 1) { // window entries r+1 .. r+32 = dwords (r+1)/2 ..; entry x <-> tap 32 + r - x
-                acc = dot2_init(we[(r + 1) / 2], pack_taps(8192, 0), bias13);
+        for (int r = 0; r < R; ++r) // window entries r+1 .. r+32 = dwords (r+1)/2 ..; entry x <-> tap 32 + r - x
+            acc[r] = (r & 1) ? dot2_init(we[(r + 1) / 2], pack_taps(8192, 0), bias13) : dot2_init(we[r / 2], pack_taps(0, 8192), bias13);
 #pragma unroll
-                for (int p = 0; p < 16; ++p) acc = dot2(wo[(r + 1) / 2 + p], pack_taps(H32(31 - 2 * p), H32(30 - 2 * p)), acc);
-            } else {
-                acc = dot2_init(we[r / 2], pack_taps(0, 8192), bias13);
-                acc = dot2(wo[r / 2], pack_taps(0, H32(31)), acc);
+        for (int t = 0; t < 17; ++t) {
 #pragma unroll
-                for (int p = 1; p < 16; ++p) acc = dot2(wo[r / 2 + p], pack_taps(H32(32 - 2 * p), H32(31 - 2 * p)), acc);
-                acc = dot2(wo[r / 2 + 16], pack_taps(H32(0), 0), acc);
+            for (int r = 0; r < R; ++r) {
+                if (r & 1) { // 16 links: dwords (r+1)/2 + p, p = 0..15
+                    if (t < 16) acc[r] = dot2_link(wo[(r + 1) / 2 + t], pack_taps(H32(31 - 2 * t), H32(30 - 2 * t)), acc[r]);
+                } else {     // 17 links: a half-used dword at either end
+                    const unsigned taps = t == 0 ? pack_taps(0, H32(31)) : (t == 16 ? pack_taps(H32(0), 0) : pack_taps(H32(32 - 2 * t), H32(31 - 2 * t)));
+                    acc[r] = dot2_link(wo[r / 2 + t], taps, acc[r]);
+                }
             }
-            res[r] = acc >> 13;
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r) res[r] = acc[r] >> 13;
     } else {
         int wo[R + 32], we[R + 4];
 #pragma unroll
@@ -175,14 +182,18 @@ template <class G, int S> __device__ __forceinline__ void run_stage(int *lds, in
             int4_t v = *reinterpret_cast<const int4_t *>(pe + k0 + 16 + x);
             we[x] = v.x; we[x + 1] = v.y; we[x + 2] = v.z; we[x + 3] = v.w;
         }
+        // acc = sum c[i] * (s[n-2i] + s[n-62+2i]) + ((s[n-31] + bias) << 13), n = 2k+1; the R chains in
+        // lockstep (tap i of every output, then tap i + 1), see above
+        int acc[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            // acc = sum c[i] * (s[n-2i] + s[n-62+2i]) + ((s[n-31] + bias) << 13), n = 2k+1
-            int acc = (int)((unsigned)(we[r + 1] + bias) << 13);
+        for (int r = 0; r < R; ++r) acc[r] = (int)((unsigned)(we[r + 1] + bias) << 13);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc = mad24(wo[r + 32 - i] + wo[r + 1 + i], C64[i], acc);
-            res[r] = acc >> 13;
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = mad24(wo[r + 32 - i] + wo[r + 1 + i], C64[i], acc[r]);
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r) res[r] = acc[r] >> 13;
     }
 
     if constexpr (LAST) {
