@@ -143,3 +143,75 @@ def test_udpsourcefec_frames(exe, oracle, tmp_path, seed):
     assert "status st:0:136/024" in lines[2]      # frame 1: 24 originals lost, 136 blocks arrived
     assert "/001" in lines[4]                     # frame 3: one recovery block used
     assert "status st:1:120/" in lines[5]         # frame 4: 40 originals lost of 160 -> 120 < 128: data lost
+
+
+def _no_gpu_env():
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""  # the adapters must fall back to "no FEC" like the reference without a valid CM256
+    env["ROCR_VISIBLE_DEVICES"] = ""
+    return env
+
+
+def test_udpsinkfec_without_gpu_sends_the_originals(exe, tmp_path):
+    """CPU: no device -> no recovery blocks (the reference's `!cm256Valid` branch, UDPSinkFEC.cpp:214-224); framing,
+    meta block, CRC, pacing thread and sockets still have to be right."""
+    nframes = 2
+    x = signals.mixed(nframes * 16129 + 17, 3)
+    fin = str(tmp_path / "in.bin")
+    x.tofile(fin)
+    port = _free_port()
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 8 << 20)
+    rx.bind(("127.0.0.1", port))
+    rx.settimeout(0.5)
+    got, stop = [], threading.Event()
+
+    def pump():
+        while not stop.is_set():
+            try:
+                got.append(rx.recv(2048))
+            except socket.timeout:
+                pass
+
+    th = threading.Thread(target=pump)
+    th.start()
+    try:
+        r = subprocess.run([exe, "tx", str(port), "32", "50", fin, "5000"], capture_output=True, text=True, timeout=120, env=_no_gpu_env())
+    finally:
+        time.sleep(0.3)
+        stop.set()
+        th.join()
+        rx.close()
+    assert r.returncode == 0 and "tx done" in r.stdout, r.stderr
+    assert len(got) == nframes * 128, (len(got), r.stderr)
+    dg = np.frombuffer(b"".join(got), np.uint8).reshape(nframes, 128, 512)
+    for f in range(nframes):
+        assert np.array_equal(dg[f, :, 2], np.arange(128))
+        fc, sr, sby, sbi, nbo, nbf, tvs, tvu, crc = struct.unpack("<IIBBBBIII", dg[f, 0, 4:28].tobytes())
+        assert (fc, sr, sby, sbi, nbo, nbf) == (435000, 625000, 2, 16, 128, 32)  # the meta block still announces fecblk
+        assert crc == zlib.crc32(dg[f, 0, 4:24].tobytes()) & 0xFFFFFFFF
+        assert np.array_equal(dg[f, 1:, 4:].reshape(-1).view(np.int16).reshape(-1, 2), x[f * 16129:(f + 1) * 16129])
+
+
+def test_udpsourcefec_without_gpu_passes_complete_frames(exe, oracle, tmp_path):
+    """CPU: frames that arrive complete need no decoder: the collector has to hand them through."""
+    x = signals.mixed(3 * 16129, 8)
+    frames = oracle.framer(nb_fec_blocks=0).write(x)
+    port = _free_port()
+    fout = str(tmp_path / "out.bin")
+    p = subprocess.Popen([exe, "rx", str(port), "4", fout], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_no_gpu_env())
+    try:
+        assert p.stdout.readline().strip() == "ready"
+        tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        for f in range(3):
+            for b in range(128):
+                tx.sendto(frames[f, b].tobytes(), ("127.0.0.1", port))
+                time.sleep(0.0002)
+        tx.sendto(bytes([0xEE]) * 512, ("127.0.0.1", port))
+        out, err = p.communicate(timeout=60)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert p.returncode == 0, err
+    got = np.fromfile(fout, np.uint8).reshape(4, 127 * 508)
+    assert np.array_equal(got[1:].reshape(-1).view(np.int16).reshape(-1, 2), x)
