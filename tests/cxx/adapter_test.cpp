@@ -11,6 +11,8 @@
 #include "Decimators.h"
 #include "Interpolators.h"
 #include "cm256.h"
+#include "Downsampler.h" // the optional boost-free Downsampler / Upsampler adapters
+#include "Upsampler.h"
 
 static std::vector<IQSample> read_iq(const char *path)
 {
@@ -99,5 +101,33 @@ int main(int argc, char **argv)
     }
     std::printf("fec roundtrip %s\n", std::memcmp(work.data(), orig.data(), orig.size()) == 0 ? "OK" : "MISMATCH");
     write_bin(argv[4], rec.data(), rec.size());
+    // --- Downsampler / Upsampler the way sdrdaemonrx.cpp:517,579-663 and sdrdaemontx.cpp:381,493 use them
+    if (argc >= 6) {
+        Downsampler dn(4, Downsampler::FC_POS_CENTER);
+        IQSampleVector s1, s2, s3, s4;
+        unsigned int s = 16;
+        dn.process(s, a, s1);
+        parsekv::pairs_type m;
+        m["decim"] = "3"; m["fcpos"] = "0";
+        if (!dn.configure(m) || dn.getLog2Decimation() != 3) return 6;
+        s = 16;
+        dn.process(s, b, s2);                       // decimate8_inf on the same filter bank
+        m.clear(); m["decim"] = "7";
+        if (dn.configure(m) || dn || dn.error() != "Invalid log2 decimation factor" || !dn) return 7; // error() clears
+        m.clear(); m["decim"] = "0";
+        if (!dn.configure(m)) return 8;
+        s = 12;
+        dn.process(s, a, s3);                       // copy + decimate1: 12-bit samples shifted to 16
+        Upsampler up(2);
+        up.process(s1, s4);
+        m.clear(); m["interp"] = "9";
+        if (up.configure(m) || up.error() != "Invalid log2 interpolation factor") return 9;
+        std::vector<IQSample> all(s1);
+        all.insert(all.end(), s2.begin(), s2.end());
+        all.insert(all.end(), s3.begin(), s3.end());
+        all.insert(all.end(), s4.begin(), s4.end());
+        write_bin(argv[5], all.data(), all.size() * 4);
+        std::printf("samplers OK %u\n", s);
+    }
     return 0;
 }

@@ -11,7 +11,7 @@ import signals
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cxx", "adapter_test.cpp")
-INC = ["-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "sdrdaemon_amd", "adapters")]
+INC = ["-I", os.path.join(ROOT, "sdrdaemon_amd", "adapters"), "-I", os.path.join(ROOT, "include")]
 
 
 def test_adapters_compile_standalone():
@@ -20,9 +20,10 @@ def test_adapters_compile_standalone():
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/include/SDRDaemon.h"), reason="reference tree not present")
 def test_adapters_compile_against_reference_headers():
+    # the adapters directory comes first, as in the CMake stub of INTEGRATION.md: Decimators.h, Interpolators.h, cm256.h,
+    # Downsampler.h, Upsampler.h are the adapters, SDRDaemon.h (IQSample) is the reference's
     for flags in (["-DUSE_SSE4_1"], []):
-        subprocess.run(["g++", "-std=c++11", "-Wall", "-fsyntax-only", "-I", "/root/reference/include"] + flags + INC + [SRC],
-                       check=True)
+        subprocess.run(["g++", "-std=c++11", "-Wall", "-fsyntax-only"] + flags + INC + ["-I", "/root/reference/include", SRC], check=True)
 
 
 @pytest.mark.gpu
@@ -37,7 +38,7 @@ def test_adapters_run_like_the_reference_call_sites(tmp_path, oracle):
     x = signals.mixed(2 * 65536, 9)
     fin = str(tmp_path / "in.bin")
     x.tofile(fin)
-    outs = [str(tmp_path / n) for n in ("dec.bin", "int.bin", "fec.bin")]
+    outs = [str(tmp_path / n) for n in ("dec.bin", "int.bin", "fec.bin", "smp.bin")]
     env = dict(os.environ, SDRHIP_HB_VARIANT="EO1")
     r = subprocess.run([exe, fin] + outs, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr
@@ -56,3 +57,11 @@ def test_adapters_run_like_the_reference_call_sites(tmp_path, oracle):
     assert np.array_equal(np.fromfile(outs[1], dtype=np.int16).reshape(-1, 2), exp_i)
     orig = x.view(np.uint8).reshape(-1)[:128 * 508].reshape(128, 508)
     assert np.array_equal(np.fromfile(outs[2], dtype=np.uint8).reshape(32, 508), oracle.cm256_encode(orig, 32))
+    # Downsampler / Upsampler adapters: decimate16_cen, reconfigured to decimate8_inf on the same bank, decim 0, interp 4
+    od2 = oracle.decimators(0)
+    s1, _ = od2.decimate(4, 2, 16, x[:65536])
+    s2, _ = od2.decimate(3, 0, 16, x[65536:])
+    s3, ss3 = od2.decimate(0, 2, 12, x[:65536])
+    assert "samplers OK %d" % ss3 in r.stdout, r.stdout  # (sampleSize after the decim-0 call)
+    s4 = oracle.interpolators().interpolate(2, s1)
+    assert np.array_equal(np.fromfile(outs[3], dtype=np.int16).reshape(-1, 2), np.concatenate([s1, s2, s3, s4]))
