@@ -269,3 +269,31 @@ def test_rx_pipe_live_reconfiguration(ctx, oracle):
                     assert np.array_equal(got[s, f, 128:], oracle.frame_encode(e[f], R)), (i, s, f)
         total += got.shape[1]
     assert total == 6
+
+
+def test_context_on_a_caller_stream(oracle):
+    """sdrhip_ctx_create(device, hipStream_t): every launch of the context goes to the caller's stream, in order with
+    the caller's own work on it (a torch side stream here), not to the default stream."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    side = torch.cuda.Stream()
+    c = sd.Context(0, stream=side)
+    S, n = 2, 3 * 16129 * 16 + 64
+    x = np.stack([signals.noise(n, 40 + s) for s in range(S)])
+    with torch.cuda.stream(side):
+        xd = torch.from_numpy(x).cuda(non_blocking=True)
+        xd = xd + 0                                    # a torch kernel on the side stream in front of ours
+        rx = sd.RxPipe(c, S, log2decim=4, nb_fec=16)
+        view = rx.process_view(xd, 1, 2)
+        frames = view.torch().clone()                  # and one behind it
+    side.synchronize()
+    frames = frames.cpu().numpy()
+    assert frames.shape[:2] == (S, 3)
+    for s in range(S):
+        y, _ = oracle.decimators(0).decimate(4, 2, 16, x[s])
+        e = oracle.framer(nb_fec_blocks=16, tv_sec=1, tv_usec=2).write(y)
+        for f in range(3):
+            assert np.array_equal(frames[s, f, :128], e[f]), (s, f)
+            assert np.array_equal(frames[s, f, 128:], oracle.frame_encode(e[f], 16)), (s, f)
