@@ -59,6 +59,10 @@ template <int OP> __global__ __launch_bounds__(256) void k(unsigned *out, int it
         if (OP == 20) { REP8(DT2) REP8(DT2) REP8(DT2) REP8(DT2) }
         if (OP == 21) { REP8(DT4) REP8(DT4) REP8(DT4) REP8(DT4) }
         if (OP == 22) { REP8(MOV) REP8(MOV) REP8(MOV) REP8(MOV) }
+#define DTL(n) asm volatile("v_dot2c_i32_i16 %0, 0xff9b0047, %1" : "+v"(a##n) : "v"(b));
+#define ADL(n) asm volatile("v_add_u32 %0, 0x12345678, %0" : "+v"(a##n));
+        if (OP == 23) { REP8(DTL) REP8(DTL) REP8(DTL) REP8(DTL) }   // 32-bit literal operand (8-byte encoding)
+        if (OP == 24) { REP8(ADL) REP8(ADL) REP8(ADL) REP8(ADL) }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
 }
@@ -111,5 +115,7 @@ int main(int argc, char **argv)
     run<20>("v_dot2_i32_i16", d);
     run<21>("v_dot4_i32_i8", d);
     run<22>("v_mov_b32", d);
+    run<23>("v_dot2c literal", d);
+    run<24>("v_add_u32 literal", d);
     return 0;
 }
