@@ -67,8 +67,8 @@ struct InterpArgs {
     int32_t *state_next;
     int nstreams;
     int nsub_per_seg, nseg;
-    // payload mode (fused Tx pipe): input sample i of a stream is read from the 127 x 508 byte
-    // payload layout directly (contiguous, so identical to linear) -- kept for symmetry
+    // (the fused Tx pipe needs no special input mode: the decoder's 127 x 508 byte payload of a frame is
+    // contiguous, i.e. already the linear sample layout)
 };
 hipError_t launch_interpolate(int log2interp, const InterpArgs &a, hipStream_t stream);
 void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_seg, int *nseg);
