@@ -348,8 +348,9 @@ def fec_decode_frames(ctx, rx, indices=None, want_block0=False):
 class _DeviceView:
     """A strided uint8 view of library-owned device memory (__cuda_array_interface__ v2)."""
 
-    def __init__(self, ptr, shape, strides, device):
+    def __init__(self, ptr, shape, strides, device, owner=None):
         self.shape, self.device = tuple(shape), device
+        self._owner = owner  # the handle whose memory this is: stays alive as long as the view (or a tensor made from it) does
         self.__cuda_array_interface__ = {"shape": tuple(shape), "strides": tuple(strides), "typestr": "|u1",
                                          "data": (ptr, False), "version": 2}
 
@@ -445,7 +446,7 @@ class RxPipe:
         base, stride, cnt = C.c_void_p(0), C.c_size_t(0), C.c_size_t(0)
         check(self.ctx.lib.sdrhip_rx_frames_view(self.h, C.byref(base), C.byref(stride), C.byref(cnt)))
         fb = (NB_ORIGINAL + self.nb_fec) * UDPSIZE
-        return _DeviceView(base.value, (S, cnt.value, NB_ORIGINAL + self.nb_fec, UDPSIZE), (stride.value, fb, UDPSIZE, 1), x.device)
+        return _DeviceView(base.value, (S, cnt.value, NB_ORIGINAL + self.nb_fec, UDPSIZE), (stride.value, fb, UDPSIZE, 1), x.device, owner=self)
 
     def close(self):
         if self.h:

@@ -297,3 +297,34 @@ def test_context_on_a_caller_stream(oracle):
         for f in range(3):
             assert np.array_equal(frames[s, f, :128], e[f]), (s, f)
             assert np.array_equal(frames[s, f, 128:], oracle.frame_encode(e[f], 16)), (s, f)
+
+
+def test_one_very_long_stream_and_a_wide_bank(ctx, oracle):
+    """Launch geometry at the extremes: one stream of 2^27 samples (2048 segments, prefix and tail against the
+    oracle) and a bank of 96 streams through the fused Rx pipe (three of them against the oracle chain)."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n = 1 << 27
+    x = torch.randint(-32768, 32768, (1, n, 2), generator=g, device="cuda", dtype=torch.int16)
+    y, _ = sd.Decimators(ctx, 1, 0).decimate(4, 2, 16, x)
+    ctx.synchronize()
+    pre, tail, skip = 1 << 21, 1 << 20, 4096  # (the cascade's memory is 930 inputs: << skip * 16)
+    e, _ = oracle.decimators(0).decimate(4, 2, 16, x[0, :pre].cpu().numpy())
+    assert np.array_equal(y[0, :pre >> 4].cpu().numpy(), e)
+    e, _ = oracle.decimators(0).decimate(4, 2, 16, x[0, n - tail:].cpu().numpy())
+    assert np.array_equal(y[0, (n >> 4) - (tail >> 4) + skip:].cpu().numpy(), e[skip:])
+    del x, y
+    S, m = 96, 1 << 19
+    xb = torch.randint(-32768, 32768, (S, m, 2), generator=g, device="cuda", dtype=torch.int16)
+    fr = sd.RxPipe(ctx, S, log2decim=4, nb_fec=32).process_view(xb, 3, 4).torch().clone()
+    ctx.synchronize()
+    assert fr.shape[:2] == (S, 2)
+    for s in (0, 47, 95):
+        yy, _ = oracle.decimators(0).decimate(4, 2, 16, xb[s].cpu().numpy())
+        ee = oracle.framer(nb_fec_blocks=32, tv_sec=3, tv_usec=4).write(yy)
+        f = fr[s].cpu().numpy()
+        for i in range(2):
+            assert np.array_equal(f[i, :128], ee[i]) and np.array_equal(f[i, 128:], oracle.frame_encode(ee[i], 32)), (s, i)
