@@ -85,11 +85,20 @@ if "tx" in what:
     tx.process(rx, idx)
     ctx.synchronize()
     t0 = time.perf_counter()
-    reps = 10
+    reps = 50
+    for _ in range(20):  # clocks ramp
+        y = tx.process(rx, idx)
+    ctx.synchronize()
+    ctx.kernel_timing(True)
+    t0 = time.perf_counter()
     for _ in range(reps):
         y = tx.process(rx, idx)
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    dms, dn = ctx.kernel_timing_read(K_FEC_DECODE)
+    ims, inn = ctx.kernel_timing_read(K_INTERPOLATE)
+    ctx.kernel_timing(False)
+    print("   of which decode kernel %.3f ms, interpolator kernel %.3f ms per step" % (dms / max(dn, 1), ims / max(inn, 1)))
     nout = Stx * F * 16129 * 16
     print("tx pipe (decode 24 erasures + interpolate16) %8.3f ms / step  %8.1f Gsamples/s out  %7.1f GB/s (4.254 B/out)" %
           (dt * 1e3, nout / dt / 1e9, nout / dt / 1e9 * 4.254))
