@@ -153,7 +153,7 @@ def _no_gpu_env():
 
 
 def test_udpsinkfec_without_gpu_sends_the_originals(exe, tmp_path):
-    """CPU: no device -> no recovery blocks (the reference's `!cm256Valid` branch, UDPSinkFEC.cpp:214-224); framing,
+    """CPU: no device -> no recovery blocks (the reference's `!cm256Valid` branch, UDPSinkFEC.cpp:218-225); framing,
     meta block, CRC, pacing thread and sockets still have to be right."""
     nframes = 2
     x = signals.mixed(nframes * 16129 + 17, 3)
