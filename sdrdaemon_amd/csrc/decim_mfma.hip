@@ -1,0 +1,368 @@
+// decim_mfma.hip -- centred half-band decimator cascades on the gfx950 matrix cores (MI355X).
+//
+// Same arithmetic as decim_kernels.hip (Decimators::decimate{2..64}_cen, Decimators.cpp:94-1305, over
+// IntHalfbandFilterEO1/DB<64>::myDecimate, IntHalfbandFilterEO1.h:100-147 / IntHalfbandFilterDB.h:79-107),
+// bit for bit, but the 32-tap polyphase FIR + centre tap of every stage is an exact integer matrix product
+// on v_mfma_i32_16x16x64_i8 instead of 34 VALU lane-ops per output (DESIGN.md "K1m"):
+//
+//  * a wave owns 16 columns = 8 consecutive spans of one stream x {I, Q}; all columns advance in lockstep,
+//    32 raw samples (16 first-stage outputs) per step.  D = A x B: the rows of A are the 16 output times of a
+//    tile, its 64 K slots hold the taps; B holds, per column, the last four 16-entry blocks of the stage's odd
+//    (FIR) or even (centre tap) input plane, one signed byte ("limb") of every entry.  Lane (column n, kq) of B
+//    holds entries 8 * (t >> 1) + 2 * kq + (t & 1) (byte t) of each block = exactly the values that lane
+//    (n, q = kq) of D produced two tiles of the previous stage ago: the whole cascade runs in registers, no
+//    LDS, no cross-lane traffic except the final I / Q pairing.
+//  * exactness: int16 input x = lo + 256 hi + 128 with signed bytes lo = (x & 255) ^ 128, hi = x >> 8 (the 128
+//    becomes a constant in the accumulator); stage outputs |v| <= 2^18 are split as v = b0 + 256 b1 + 65536 b2
+//    with signed bytes b = bytes of (v + 0x808080) ^ 0x808080; taps h = h0 + 256 h1.  The limb products of
+//    equal weight share an accumulator (|sum| < 2^21: no overflow), the four accumulators are recombined with
+//    shifts modulo 2^32 = the reference's wrap-around int32 sum.  The centre tap 8192 = 32 * 256 rides along as
+//    one more limb product on the even plane.
+//  * the newest block of a window replaces the oldest in place (dword `phase` of the fragment), the tap
+//    matrices exist in the four rotations; the multi-rate schedule (stage s runs every 2^s steps) is unrolled
+//    over one period of 4 * 2^(NS-1) steps so that every phase is a compile-time constant.
+//  * a span is preceded by one period (64 * 2^L raw samples) of warm-up with stores suppressed, exactly like
+//    the VALU kernel's segments.  Head [0, head) and tail of every stream go through the VALU code
+//    (decim_body.h) in the same launch: it owns the bank state (load at the start, store at the end).
+#include "decim_body.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace sdrhip {
+namespace {
+
+// slot (lane kq, byte t) of a 16-entry block <-> entry index inside the block
+__host__ __device__ constexpr int mf_entry(int kq, int t) { return 8 * (t >> 1) + 2 * kq + (t & 1); }
+
+struct MfATab {
+    unsigned w[3][4][64][4]; // matrix (h0, h1, centre) x phase x lane x dword
+};
+
+constexpr MfATab mf_make_atab()
+{
+    MfATab T{};
+    for (int m = 0; m < 3; ++m)
+        for (int ph = 0; ph < 4; ++ph)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, kq = lane >> 4;
+                for (int j = 0; j < 4; ++j) {
+                    const int beta = (ph - j) & 3; // dword j holds the block `beta` blocks before the newest
+                    unsigned word = 0;
+                    for (int t = 0; t < 4; ++t) {
+                        const int d = r - mf_entry(kq, t) + 16 * beta; // delay of the entry w.r.t. output r, in plane entries
+                        int v = 0;
+                        if (m < 2) {
+                            if (d >= 0 && d <= 31) {
+                                const int h = H32(d);
+                                const int h1 = (h + 128) >> 8, h0 = h - 256 * h1;
+                                v = m == 0 ? h0 : h1;
+                            }
+                        } else {
+                            v = (d == 15) ? 32 : 0; // centre tap 8192 = 32 * 256 on the even plane, IntHalfbandFilterEO1.h:136-142
+                        }
+                        word |= (unsigned)(v & 0xff) << (8 * t);
+                    }
+                    T.w[m][ph][lane][j] = word;
+                }
+            }
+    return T;
+}
+
+__device__ const MfATab mf_atab = mf_make_atab();
+
+constexpr int mf_tap_sum()
+{
+    int s = 0;
+    for (int i = 0; i < 32; ++i) s += H32(i);
+    return s + 8192;
+}
+
+template <class F, int... Is> __device__ __forceinline__ void mf_static_for_impl(F &&f, std::integer_sequence<int, Is...>)
+{
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void mf_static_for(F &&f)
+{
+    mf_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ int4_t mfma(int4_t a, int4_t b, int4_t c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+template <int NS> struct MfState {
+    int4_t O[NS][3];           // odd plane window of every stage, one signed byte per entry and limb
+    int4_t E[NS][3];           // even plane window
+    unsigned pend[NS][2][2];   // inputs of stage s >= 1: first half of the block being formed ([parity][limbs 0-1, limb 2])
+};
+
+struct MfConst {
+    int4_t A[3][4]; // tap matrices (h0, h1, centre) in the four rotations
+    int4_t cin0;    // accumulator start of stage 0: 128 * (sum of taps) + (bias << 13)
+    int4_t cinN;    // other stages: bias << 13
+};
+
+struct MfOut {
+    unsigned *p;          // plain mode: where this lane's next four outputs go; frame mode: stream's frame area
+    int store;            // 0 during warm-up
+    int norm, trunk;
+    int frame_mode;
+    unsigned w;           // frame mode: position of the lane's next output inside its frame (0..16128)
+    size_t fdw;           // frame mode: dword offset of that frame
+    size_t frame_dw;      // dwords per frame slot
+};
+
+template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState<NS> &st, const MfConst &k, MfOut &oc, int comp)
+{
+    constexpr int PH = I & 3;
+    const int4_t Ah0 = k.A[0][PH], Ah1 = k.A[1][PH], Ac = k.A[2][PH];
+    const int4_t z = {0, 0, 0, 0};
+    int o[4];
+    if constexpr (S == 0) {
+        int4_t g0 = mfma(Ah0, st.O[0][0], k.cin0);
+        int4_t g1 = mfma(Ah0, st.O[0][1], z);
+        int4_t g2 = mfma(Ah1, st.O[0][1], z);
+        g1 = mfma(Ah1, st.O[0][0], g1);
+        g2 = mfma(Ac, st.E[0][1], g2);
+        g1 = mfma(Ac, st.E[0][0], g1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (int)((unsigned)g0[r] + ((unsigned)g1[r] << 8) + ((unsigned)g2[r] << 16)) >> 13;
+    } else {
+        int4_t g0 = mfma(Ah0, st.O[S][0], k.cinN);
+        int4_t g1 = mfma(Ah0, st.O[S][1], z);
+        int4_t g2 = mfma(Ah0, st.O[S][2], z);
+        int4_t g3 = mfma(Ah1, st.O[S][2], z);
+        g1 = mfma(Ah1, st.O[S][0], g1);
+        g2 = mfma(Ah1, st.O[S][1], g2);
+        g3 = mfma(Ac, st.E[S][2], g3);
+        g1 = mfma(Ac, st.E[S][0], g1);
+        g2 = mfma(Ac, st.E[S][1], g2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            o[r] = (int)((unsigned)g0[r] + ((unsigned)g1[r] << 8) + ((unsigned)g2[r] << 16) + ((unsigned)g3[r] << 24)) >> 13;
+    }
+
+    if constexpr (S < NS - 1) {
+        // outputs 4q .. 4q+3 of this tile: r = 0, 2 are even inputs of stage S+1, r = 1, 3 odd ones
+        constexpr int SIG = I & 1, NJ = (I >> 1) & 3;
+        unsigned u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = (unsigned)o[r] + 0x808080u;
+        const unsigned pe = perm(u[2], u[0], 0x05010400u), pe2 = perm(u[2], u[0], 0x0c0c0602u);
+        const unsigned po = perm(u[3], u[1], 0x05010400u), po2 = perm(u[3], u[1], 0x0c0c0602u);
+        if constexpr (SIG == 0) {
+            st.pend[S + 1][0][0] = pe; st.pend[S + 1][0][1] = pe2;
+            st.pend[S + 1][1][0] = po; st.pend[S + 1][1][1] = po2;
+        } else {
+            const unsigned X = 0x80808080u;
+            st.E[S + 1][0][NJ] = (int)(perm(pe, st.pend[S + 1][0][0], 0x05040100u) ^ X);
+            st.E[S + 1][1][NJ] = (int)(perm(pe, st.pend[S + 1][0][0], 0x07060302u) ^ X);
+            st.E[S + 1][2][NJ] = (int)(perm(pe2, st.pend[S + 1][0][1], 0x05040100u) ^ X);
+            st.O[S + 1][0][NJ] = (int)(perm(po, st.pend[S + 1][1][0], 0x05040100u) ^ X);
+            st.O[S + 1][1][NJ] = (int)(perm(po, st.pend[S + 1][1][0], 0x07060302u) ^ X);
+            st.O[S + 1][2][NJ] = (int)(perm(po2, st.pend[S + 1][1][1], 0x05040100u) ^ X);
+            mf_stage<NS, S + 1, (I >> 1)>(st, k, oc, comp);
+        }
+    } else {
+        // lanes n = 2p (I) and 2p + 1 (Q) hold the same outputs: the I lane packs and stores
+        unsigned pk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int other = __builtin_amdgcn_update_dpp(0, o[r], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+            pk[r] = final_pack(o[r], other, oc.norm, oc.trunk);
+        }
+        if (oc.store && comp == 0) {
+            if (!oc.frame_mode) {
+                *reinterpret_cast<uint4_t *>(oc.p) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
+            } else {
+                // UDPSinkFEC::write framing (UDPSinkFEC.cpp:134-155), see store_one() in decim_body.h
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    unsigned w2 = oc.w + r;
+                    size_t f2 = oc.fdw;
+                    if (w2 >= 16129u) { w2 -= 16129u; f2 += oc.frame_dw; }
+                    const unsigned b = w2 / 127u, i = w2 - b * 127u;
+                    oc.p[f2 + (size_t)(1u + b) * 128u + 1u + i] = pk[r];
+                }
+            }
+        }
+        if (oc.store) {
+            if (!oc.frame_mode) {
+                oc.p += 16;
+            } else {
+                oc.w += 16;
+                if (oc.w >= 16129u) { oc.w -= 16129u; oc.fdw += oc.frame_dw; }
+            }
+        }
+    }
+}
+
+template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw)
+{
+    constexpr int L = NS;
+    constexpr int P = 4 << (NS - 1);    // first-stage steps per period
+    constexpr int D = 4;                // steps of loads in flight
+    constexpr size_t W = (size_t)64 << L; // warm-up = one period, raw samples
+    static_assert(P % D == 0, "prefetch ring");
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 15, q = lane >> 4, comp = n & 1, p = n >> 1;
+    const int stream = gw / a.mf_wps, ws = gw - stream * a.mf_wps;
+    const size_t S = a.mf_span;
+    const size_t wave_start = a.mf_head + (size_t)ws * 8 * S; // first stored raw sample of column pair 0
+    const char *wbase = reinterpret_cast<const char *>(a.in) + ((size_t)stream * a.in_stride + wave_start - W) * 4;
+    const unsigned loff = (unsigned)((size_t)p * S * 4) + 16u * (unsigned)q;
+    const int T = (int)((W + S) / 32); // steps
+    const int nper = T / P;
+
+    MfConst k;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) k.A[m][ph] = *reinterpret_cast<const int4_t *>(&mf_atab.w[m][ph][lane][0]);
+    const int b13 = a.bias << 13;
+    const int c0 = (int)(128u * (unsigned)mf_tap_sum()) + b13;
+    k.cin0 = (int4_t){c0, c0, c0, c0};
+    k.cinN = (int4_t){b13, b13, b13, b13};
+
+    MfOut oc;
+    oc.store = 0;
+    oc.norm = a.norm; oc.trunk = a.trunk;
+    oc.frame_mode = a.frame_mode;
+    oc.frame_dw = (size_t)a.frame_blocks * 128u;
+    {
+        unsigned *obase = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
+        const size_t first = ((wave_start + (size_t)p * S) >> L) + 4u * (unsigned)q; // this lane's first output
+        if (!a.frame_mode) {
+            oc.p = obase + first;
+            oc.w = 0; oc.fdw = 0;
+        } else {
+            const uint64_t g = a.frame_sample_base + first;
+            const uint64_t f = g / 16129u;
+            oc.p = obase;
+            oc.w = (unsigned)(g - f * 16129u);
+            oc.fdw = (size_t)f * oc.frame_dw;
+        }
+    }
+
+    MfState<NS> st;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { st.O[s][b] = (int4_t){0, 0, 0, 0}; st.E[s][b] = (int4_t){0, 0, 0, 0}; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { st.pend[s][0][0] = st.pend[s][0][1] = st.pend[s][1][0] = st.pend[s][1][1] = 0u; }
+
+    const unsigned selc = comp ? 0x07030602u : 0x05010400u;
+    uint4_t ld[D][2];
+    auto issue = [&](int slot, int g) {
+        const char *src = wbase + (size_t)g * 128u + loff;
+        ld[slot][0] = *reinterpret_cast<const uint4_t *>(src);
+        ld[slot][1] = *reinterpret_cast<const uint4_t *>(src + 64);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d, d < T ? d : T - 1);
+
+    for (int per = 0; per < nper; ++per) {
+        oc.store = per > 0;
+        const int g0 = per * P;
+        mf_static_for<P>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int slot = i % D;
+            const uint4_t r0 = ld[slot][0], r1 = ld[slot][1];
+            {
+                int g = g0 + i + D;
+                g = g < T ? g : T - 1;
+                issue(slot, g);
+            }
+            // raw samples 4q .. 4q+3 (r0) and 16 + 4q .. (r1) of the step's 32: x, z even; y, w odd
+            const unsigned ao = perm(r0.w, r0.y, selc), bo = perm(r1.w, r1.y, selc);
+            const unsigned ae = perm(r0.z, r0.x, selc), be = perm(r1.z, r1.x, selc);
+            const unsigned X = 0x80808080u;
+            st.O[0][0][i & 3] = (int)(perm(bo, ao, 0x05040100u) ^ X);
+            st.O[0][1][i & 3] = (int)perm(bo, ao, 0x07060302u);
+            st.E[0][0][i & 3] = (int)(perm(be, ae, 0x05040100u) ^ X);
+            st.E[0][1][i & 3] = (int)perm(be, ae, 0x07060302u);
+            mf_stage<NS, 0, i>(st, k, oc, comp);
+        });
+    }
+}
+
+// grid.x = nstreams * mf_npieces VALU workgroups (head + tail pieces of every stream), then the matrix-core
+// workgroups (four waves = four groups of 8 spans each)
+template <int L, bool PACK16> __global__ __launch_bounds__(NT, 2) void decim_mfma_kernel(DecimArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int lds[DecimLds<L, 2, PACK16>::dwords];
+    const int nleg = a.nstreams * a.mf_npieces;
+    const int bx = blockIdx.x;
+    if (bx < nleg) {
+        const int stream = bx / a.mf_npieces, piece = bx - stream * a.mf_npieces;
+        if (piece == 0) {
+            decim_piece<L, 2, PACK16>(a, lds, stream, 0, a.mf_head, true, false, piece, a.mf_npieces);
+        } else {
+            const size_t s0 = a.mf_tail_start + (size_t)(piece - 1) * a.mf_tail_seg;
+            size_t s1 = s0 + a.mf_tail_seg;
+            if (s1 > a.n_used || piece == a.mf_npieces - 1) s1 = a.n_used;
+            decim_piece<L, 2, PACK16>(a, lds, stream, s0, s1, false, piece == a.mf_npieces - 1, piece, a.mf_npieces);
+        }
+        return;
+    }
+    const int gw = __builtin_amdgcn_readfirstlane((bx - nleg) * 4 + (int)(threadIdx.x >> 6));
+    if (gw >= a.nstreams * a.mf_wps) return;
+    mf_wave<L>(a, gw);
+}
+
+template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream_t stream)
+{
+    const int nleg = a.nstreams * a.mf_npieces;
+    const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
+    if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true>), dim3(nleg + nmf), dim3(NT), 0, stream, a);
+    else hipLaunchKernelGGL((decim_mfma_kernel<L, false>), dim3(nleg + nmf), dim3(NT), 0, stream, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, size_t span_override, DecimArgs *a)
+{
+    if (fcpos != 2 || log2decim < 2 || log2decim > 4) return false;
+    const size_t W = (size_t)64 << log2decim;     // one period of the schedule = the warm-up
+    const size_t head = W > 2048 ? W : 2048;      // VALU head piece: whole passes, >= the warm-up of the first span
+    if (n_used <= head) return false;
+    const size_t n = n_used - head;
+    size_t S;
+    if (span_override) {
+        S = (span_override + W - 1) / W * W;
+    } else {
+        // one round of 2 waves per SIMD (2048 waves of 8 spans) when the call is big enough; longer spans beyond
+        S = (n * (size_t)nstreams / (2048 * 8)) / W * W;
+        if (S < 16 * W) S = 16 * W;               // warm-up <= 6 %
+        if (S > 256 * W) S = 256 * W;
+    }
+    const size_t wps = n / (8 * S);
+    if (wps == 0 || wps > 0x7fffffffu / (size_t)nstreams) return false;
+    if (8 * S * 4 >= 0xffffffffu) return false;   // lane offsets inside a wave are 32 bits
+    const size_t tail_start = head + wps * 8 * S;
+    const size_t tail = n_used - tail_start;
+    const size_t seg = 16384;                     // 8 passes of the VALU code per tail piece
+    size_t ntail = (tail + seg - 1) / seg;
+    if (ntail == 0) ntail = 1;                    // the (possibly empty) last piece stores the bank state
+    a->mf_head = head;
+    a->mf_span = S;
+    a->mf_wps = (int)wps;
+    a->mf_tail_start = tail_start;
+    a->mf_tail_seg = seg;
+    a->mf_npieces = 1 + (int)ntail;
+    return true;
+}
+
+hipError_t launch_decimate_mfma(int log2decim, bool pack16, const DecimArgs &a, hipStream_t stream)
+{
+    switch (log2decim) {
+    case 2: return launch_mf<2>(pack16, a, stream);
+    case 3: return launch_mf<3>(pack16, a, stream);
+    case 4: return launch_mf<4>(pack16, a, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+} // namespace sdrhip

@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -254,6 +255,26 @@ extern "C" int sdrhip_decimators_reset(sdrhip_decimators *d)
     return SDRHIP_OK;
 }
 
+namespace {
+enum { DECIM_PATH_AUTO = 0, DECIM_PATH_VALU = 1, DECIM_PATH_MFMA = 2 };
+struct DecimPathEnv {
+    int path;
+    size_t span, min_samples;
+};
+DecimPathEnv decim_path_env()
+{
+    DecimPathEnv e;
+    e.path = DECIM_PATH_AUTO; e.span = 0; e.min_samples = (size_t)1 << 22;
+    if (const char *p = getenv("SDRHIP_DECIM_PATH")) {
+        if (!strcmp(p, "valu")) e.path = DECIM_PATH_VALU;
+        else if (!strcmp(p, "mfma")) e.path = DECIM_PATH_MFMA;
+    }
+    if (const char *p = getenv("SDRHIP_MFMA_SPAN")) e.span = (size_t)strtoull(p, nullptr, 10);
+    if (const char *p = getenv("SDRHIP_MFMA_MIN")) e.min_samples = (size_t)strtoull(p, nullptr, 10);
+    return e;
+}
+} // namespace
+
 namespace sdrhip {
 // device-pointer core shared with the fused Rx pipe; frame_* = 0 for plain output
 int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in,
@@ -303,10 +324,16 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     plan_decimate((int)L, fcpos, a.n_used, d->nstreams, &a.nsub_per_seg, &a.nseg);
     const bool cen = (fcpos == SDRHIP_FC_CEN);
     const bool pack16 = cen && d->stage0_int16;
+    // matrix-core cascade for the centred modes when the call is long enough to fill the chip;
+    // SDRHIP_DECIM_PATH = valu | mfma | auto (default), SDRHIP_MFMA_SPAN = span length in samples (tests)
+    const DecimPathEnv env = decim_path_env(); // (read per call: tests switch paths inside one process)
+    bool use_mfma = false;
+    if (env.path != DECIM_PATH_VALU && (env.path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= env.min_samples))
+        use_mfma = plan_decimate_mfma((int)L, fcpos, a.n_used, d->nstreams, env.span, &a);
     hipError_t e;
     {
         KTimer kt(c, SDRHIP_K_DECIMATE);
-        e = launch_decimate((int)L, fcpos, pack16, a, c->stream);
+        e = use_mfma ? launch_decimate_mfma((int)L, pack16, a, c->stream) : launch_decimate((int)L, fcpos, pack16, a, c->stream);
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "decimate launch: %s", hipGetErrorString(e));
     d->cur ^= 1;

@@ -46,12 +46,22 @@ struct DecimArgs {
     int meta_first, meta_count;
     unsigned meta_frame_count0;
     unsigned meta_w[6];
+    // matrix-core launch (decim_mfma.hip): per stream the VALU code runs the head [0, mf_head) and the tail
+    // [mf_tail_start, n_used) in pieces of mf_tail_seg samples (mf_npieces = 1 + tail pieces workgroups), the
+    // matrix-core waves run mf_wps groups of 8 spans of mf_span raw samples from mf_head on
+    size_t mf_head, mf_span, mf_tail_start, mf_tail_seg;
+    int mf_wps, mf_npieces;
 };
 
 // returns hipSuccess or the launch error
 hipError_t launch_decimate(int log2decim, int fcpos, bool pack16, const DecimArgs &a, hipStream_t stream);
 // picks nsub_per_seg / nseg for a call (host helper living next to the kernel's geometry)
 void plan_decimate(int log2decim, int fcpos, size_t n_used, int nstreams, int *nsub_per_seg, int *nseg);
+
+// matrix-core variant of the centred cascades: fills the mf_* fields, false when the call is too short (or the
+// mode unsupported); span_override != 0 forces the span length (tests)
+bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, size_t span_override, DecimArgs *a);
+hipError_t launch_decimate_mfma(int log2decim, bool pack16, const DecimArgs &a, hipStream_t stream);
 
 // filter-less paths: log2decim 0 (decimate1) and inf/sup 2, 4 (Decimators.cpp:22-91,127-170)
 hipError_t launch_decimate_simple(int log2decim, int fcpos, const int16_t *in, size_t in_stride, int16_t *out,
