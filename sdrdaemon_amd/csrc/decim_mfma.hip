@@ -10,14 +10,17 @@
 //    tile, its 64 K slots hold the taps; B holds, per column, the last four 16-entry blocks of the stage's odd
 //    (FIR) or even (centre tap) input plane, one signed byte ("limb") of every entry.  Lane (column n, kq) of B
 //    holds entries 8 * (t >> 1) + 2 * kq + (t & 1) (byte t) of each block = exactly the values that lane
-//    (n, q = kq) of D produced two tiles of the previous stage ago: the whole cascade runs in registers, no
-//    LDS, no cross-lane traffic except the final I / Q pairing.
+//    (n, q = kq) of D produced two tiles of the previous stage ago: the FIR data path runs in registers, no
+//    cross-lane traffic except the centre-tap ring below and the final I / Q pairing.
 //  * exactness: int16 input x = lo + 256 hi + 128 with signed bytes lo = (x & 255) ^ 128, hi = x >> 8 (the 128
 //    becomes a constant in the accumulator); stage outputs |v| <= 2^18 are split as v = b0 + 256 b1 + 65536 b2
 //    with signed bytes b = bytes of (v + 0x808080) ^ 0x808080; taps h = h0 + 256 h1.  The limb products of
 //    equal weight share an accumulator (|sum| < 2^21: no overflow), the four accumulators are recombined with
-//    shifts modulo 2^32 = the reference's wrap-around int32 sum.  The centre tap 8192 = 32 * 256 rides along as
-//    one more limb product on the even plane.
+//    shifts modulo 2^32 = the reference's wrap-around int32 sum.
+//  * the centre tap (x[2k - 30] << 13) needs no multiplier: the even outputs of a stage (even raw samples for the
+//    first stage) go as int32 through a 32-entry ring per column and stage in LDS (written by the lane that
+//    produced them, read four at a time by the lane that owns outputs k .. k+3) and enter the accumulator as
+//    (e << 13) + c.  The ring is private to the wave: no barrier, program order of the wave's DS operations.
 //  * the newest block of a window replaces the oldest in place (dword `phase` of the fragment), the tap
 //    matrices exist in the four rotations; the multi-rate schedule (stage s runs every 2^s steps) is unrolled
 //    over one period of 4 * 2^(NS-1) steps so that every phase is a compile-time constant.
@@ -36,13 +39,13 @@ namespace {
 __host__ __device__ constexpr int mf_entry(int kq, int t) { return 8 * (t >> 1) + 2 * kq + (t & 1); }
 
 struct MfATab {
-    unsigned w[3][4][64][4]; // matrix (h0, h1, centre) x phase x lane x dword
+    unsigned w[2][4][64][4]; // tap limb (h0, h1) x phase x lane x dword
 };
 
 constexpr MfATab mf_make_atab()
 {
     MfATab T{};
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 2; ++m)
         for (int ph = 0; ph < 4; ++ph)
             for (int lane = 0; lane < 64; ++lane) {
                 const int r = lane & 15, kq = lane >> 4;
@@ -52,14 +55,10 @@ constexpr MfATab mf_make_atab()
                     for (int t = 0; t < 4; ++t) {
                         const int d = r - mf_entry(kq, t) + 16 * beta; // delay of the entry w.r.t. output r, in plane entries
                         int v = 0;
-                        if (m < 2) {
-                            if (d >= 0 && d <= 31) {
-                                const int h = H32(d);
-                                const int h1 = (h + 128) >> 8, h0 = h - 256 * h1;
-                                v = m == 0 ? h0 : h1;
-                            }
-                        } else {
-                            v = (d == 15) ? 32 : 0; // centre tap 8192 = 32 * 256 on the even plane, IntHalfbandFilterEO1.h:136-142
+                        if (d >= 0 && d <= 31) {
+                            const int h = H32(d);
+                            const int h1 = (h + 128) >> 8, h0 = h - 256 * h1;
+                            v = m == 0 ? h0 : h1;
                         }
                         word |= (unsigned)(v & 0xff) << (8 * t);
                     }
@@ -75,7 +74,7 @@ constexpr int mf_tap_sum()
 {
     int s = 0;
     for (int i = 0; i < 32; ++i) s += H32(i);
-    return s + 8192;
+    return s;
 }
 
 template <class F, int... Is> __device__ __forceinline__ void mf_static_for_impl(F &&f, std::integer_sequence<int, Is...>)
@@ -90,114 +89,144 @@ template <int N, class F> __device__ __forceinline__ void mf_static_for(F &&f)
 __device__ __forceinline__ int4_t mfma(int4_t a, int4_t b, int4_t c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
+// centre-tap ring (LDS, private to a wave): [stage][column][MF_RING_PITCH] int32; entry m of a stage's even
+// input plane sits at position m & 31
+constexpr int MF_RING_PITCH = 36;                      // dwords per column (32 + pad: 16-byte aligned, spreads the banks)
+constexpr int MF_RING_STAGE = 16 * MF_RING_PITCH;      // dwords per stage
+template <int NS> constexpr int mf_ring_dwords() { return 4 * NS * MF_RING_STAGE; } // per workgroup of four waves
+
 template <int NS> struct MfState {
-    int4_t O[NS][3];           // odd plane window of every stage, one signed byte per entry and limb
-    int4_t E[NS][3];           // even plane window
-    unsigned pend[NS][2][2];   // inputs of stage s >= 1: first half of the block being formed ([parity][limbs 0-1, limb 2])
+    int4_t O[NS][3];        // odd plane window of every stage, one signed byte per entry and limb
+    unsigned pend[NS][2];   // odd inputs of stage s >= 1: first half of the block being formed (limbs 0-1, limb 2)
 };
 
 struct MfConst {
-    int4_t A[3][4]; // tap matrices (h0, h1, centre) in the four rotations
-    int4_t cin0;    // accumulator start of stage 0: 128 * (sum of taps) + (bias << 13)
-    int4_t cinN;    // other stages: bias << 13
+    int4_t A[2][4]; // tap matrices (limbs h0, h1) in the four rotations
+    int cin0;       // accumulator start of stage 0: 128 * (sum of the FIR taps) + (bias << 13)
+    int cinN;       // other stages: bias << 13
+    int *ring_wr;   // ring + column + 2 * q dwords: where this lane's even entries 2q, 2q+1 of a group of 8 go
+    int *ring_rd;   // ring + column + 4 * q dwords: entries 4q .. 4q+3 of a block
+    int *ring_rd4b; // entry 4q+4 of the odd-numbered block (wraps to entry 0 of the even one for q = 3)
 };
 
 struct MfOut {
     unsigned *p;          // plain mode: where this lane's next four outputs go; frame mode: stream's frame area
+    unsigned *dump;       // 16 bytes per lane that swallow the stores of the warm-up period (no branch in the loop body)
     int store;            // 0 during warm-up
     int norm, trunk;
-    int frame_mode;
     unsigned w;           // frame mode: position of the lane's next output inside its frame (0..16128)
     size_t fdw;           // frame mode: dword offset of that frame
     size_t frame_dw;      // dwords per frame slot
 };
 
-template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState<NS> &st, const MfConst &k, MfOut &oc, int comp)
+__device__ __forceinline__ int sbfe16(unsigned v, int off) { return (int)__builtin_amdgcn_sbfe((int)v, (unsigned)off, 16u); }
+
+// (a << sh) + b = one v_lshl_add_u32.  Plain C on purpose: the operands come straight out of MFMAs and go into MFMAs,
+// and hipcc pads those hazards only for instructions it emits itself, not for inline asm.  The limb accumulators are
+// recombined in Horner form ((g3 << 8) + g2) << 8 ... so that every step is exactly one shift-add (a flat sum of
+// shifted terms compiles to v_lshlrev + v_add3 pairs: one op more per output).
+__device__ __forceinline__ unsigned lshl_add(unsigned a, int sh, unsigned b) { return (a << sh) + b; }
+// keeps hipcc from re-associating a Horner chain back into a flat sum: the partial result (a VALU result, never a raw
+// MFMA output) becomes opaque; the statement holds no instruction
+__device__ __forceinline__ unsigned opaque(unsigned v)
+{
+    asm("" : "+v"(v));
+    return v;
+}
+
+// accumulator start of outputs 4q .. 4q+3 of tile I of stage S: c + (e << 13) with e = even-plane entry k - 15
+// (IntHalfbandFilterEO1.h:136-142); entries 16 (I-1) + 4q+1 .. 4q+4 of the ring
+template <int S, int I> __device__ __forceinline__ int4_t mf_centre(const MfConst &k, int c)
+{
+    constexpr int BP = (I + 3) & 1; // parity of block I - 1
+    // the entries were written by OTHER lanes of this wave: the compiler must not move the reads above ring stores
+    // it can prove disjoint per lane (the hardware executes a wave's DS operations in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int *rd = k.ring_rd + S * MF_RING_STAGE + 16 * BP;
+    const int4_t v = *reinterpret_cast<const int4_t *>(rd);
+    const int e4 = BP ? k.ring_rd4b[S * MF_RING_STAGE] : rd[4];
+    int4_t r;
+    r[0] = (int)lshl_add((unsigned)v[1], 13, (unsigned)c);
+    r[1] = (int)lshl_add((unsigned)v[2], 13, (unsigned)c);
+    r[2] = (int)lshl_add((unsigned)v[3], 13, (unsigned)c);
+    r[3] = (int)lshl_add((unsigned)e4, 13, (unsigned)c);
+    return r;
+}
+
+template <int NS, bool FRAME, int S, int I> __device__ __forceinline__ void mf_stage(MfState<NS> &st, const MfConst &k, MfOut &oc, int comp)
 {
     constexpr int PH = I & 3;
-    const int4_t Ah0 = k.A[0][PH], Ah1 = k.A[1][PH], Ac = k.A[2][PH];
+    const int4_t Ah0 = k.A[0][PH], Ah1 = k.A[1][PH];
     const int4_t z = {0, 0, 0, 0};
     int o[4];
     if constexpr (S == 0) {
-        int4_t g0 = mfma(Ah0, st.O[0][0], k.cin0);
+        int4_t g0 = mfma(Ah0, st.O[0][0], mf_centre<0, I>(k, k.cin0));
         int4_t g1 = mfma(Ah0, st.O[0][1], z);
         int4_t g2 = mfma(Ah1, st.O[0][1], z);
         g1 = mfma(Ah1, st.O[0][0], g1);
-        g2 = mfma(Ac, st.E[0][1], g2);
-        g1 = mfma(Ac, st.E[0][0], g1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (int)((unsigned)g0[r] + ((unsigned)g1[r] << 8) + ((unsigned)g2[r] << 16)) >> 13;
+        for (int r = 0; r < 4; ++r) o[r] = (int)lshl_add(opaque(lshl_add((unsigned)g2[r], 8, (unsigned)g1[r])), 8, (unsigned)g0[r]) >> 13;
     } else {
-        int4_t g0 = mfma(Ah0, st.O[S][0], k.cinN);
+        int4_t g0 = mfma(Ah0, st.O[S][0], mf_centre<S, I>(k, k.cinN));
         int4_t g1 = mfma(Ah0, st.O[S][1], z);
         int4_t g2 = mfma(Ah0, st.O[S][2], z);
         int4_t g3 = mfma(Ah1, st.O[S][2], z);
         g1 = mfma(Ah1, st.O[S][0], g1);
         g2 = mfma(Ah1, st.O[S][1], g2);
-        g3 = mfma(Ac, st.E[S][2], g3);
-        g1 = mfma(Ac, st.E[S][0], g1);
-        g2 = mfma(Ac, st.E[S][1], g2);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            o[r] = (int)((unsigned)g0[r] + ((unsigned)g1[r] << 8) + ((unsigned)g2[r] << 16) + ((unsigned)g3[r] << 24)) >> 13;
+            o[r] = (int)lshl_add(opaque(lshl_add(opaque(lshl_add((unsigned)g3[r], 8, (unsigned)g2[r])), 8, (unsigned)g1[r])), 8, (unsigned)g0[r]) >> 13;
     }
 
     if constexpr (S < NS - 1) {
-        // outputs 4q .. 4q+3 of this tile: r = 0, 2 are even inputs of stage S+1, r = 1, 3 odd ones
+        // outputs 4q .. 4q+3 of this tile: r = 0, 2 are even inputs of stage S+1 (entries 8 I + 2q, + 1 of its even
+        // plane: to the ring), r = 1, 3 odd ones (to the window, one signed byte per limb)
         constexpr int SIG = I & 1, NJ = (I >> 1) & 3;
-        unsigned u[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = (unsigned)o[r] + 0x808080u;
-        const unsigned pe = perm(u[2], u[0], 0x05010400u), pe2 = perm(u[2], u[0], 0x0c0c0602u);
-        const unsigned po = perm(u[3], u[1], 0x05010400u), po2 = perm(u[3], u[1], 0x0c0c0602u);
+        *reinterpret_cast<int2_t *>(k.ring_wr + (S + 1) * MF_RING_STAGE + 8 * (I & 3)) = (int2_t){o[0], o[2]};
+        const unsigned u1 = (unsigned)o[1] + 0x808080u, u3 = (unsigned)o[3] + 0x808080u;
+        const unsigned po = perm(u3, u1, 0x05010400u), po2 = perm(u3, u1, 0x0c0c0602u);
         if constexpr (SIG == 0) {
-            st.pend[S + 1][0][0] = pe; st.pend[S + 1][0][1] = pe2;
-            st.pend[S + 1][1][0] = po; st.pend[S + 1][1][1] = po2;
+            st.pend[S + 1][0] = po; st.pend[S + 1][1] = po2;
         } else {
             const unsigned X = 0x80808080u;
-            st.E[S + 1][0][NJ] = (int)(perm(pe, st.pend[S + 1][0][0], 0x05040100u) ^ X);
-            st.E[S + 1][1][NJ] = (int)(perm(pe, st.pend[S + 1][0][0], 0x07060302u) ^ X);
-            st.E[S + 1][2][NJ] = (int)(perm(pe2, st.pend[S + 1][0][1], 0x05040100u) ^ X);
-            st.O[S + 1][0][NJ] = (int)(perm(po, st.pend[S + 1][1][0], 0x05040100u) ^ X);
-            st.O[S + 1][1][NJ] = (int)(perm(po, st.pend[S + 1][1][0], 0x07060302u) ^ X);
-            st.O[S + 1][2][NJ] = (int)(perm(po2, st.pend[S + 1][1][1], 0x05040100u) ^ X);
-            mf_stage<NS, S + 1, (I >> 1)>(st, k, oc, comp);
+            st.O[S + 1][0][NJ] = (int)(perm(po, st.pend[S + 1][0], 0x05040100u) ^ X);
+            st.O[S + 1][1][NJ] = (int)(perm(po, st.pend[S + 1][0], 0x07060302u) ^ X);
+            st.O[S + 1][2][NJ] = (int)(perm(po2, st.pend[S + 1][1], 0x05040100u) ^ X);
+            mf_stage<NS, FRAME, S + 1, (I >> 1)>(st, k, oc, comp);
         }
     } else {
-        // lanes n = 2p (I) and 2p + 1 (Q) hold the same outputs: the I lane packs and stores
+        // lanes n = 2p (I) and 2p + 1 (Q) hold the same outputs: both pack the same dwords and store them to the
+        // same place (no divergence, no branch: the loop body stays one basic block and hipcc's vmcnt waits stay
+        // exact); the warm-up period stores into the dump slot
         unsigned pk[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int other = __builtin_amdgcn_update_dpp(0, o[r], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
-            pk[r] = final_pack(o[r], other, oc.norm, oc.trunk);
+            pk[r] = final_pack(comp ? other : o[r], comp ? o[r] : other, oc.norm, oc.trunk);
         }
-        if (oc.store && comp == 0) {
-            if (!oc.frame_mode) {
-                *reinterpret_cast<uint4_t *>(oc.p) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
-            } else {
-                // UDPSinkFEC::write framing (UDPSinkFEC.cpp:134-155), see store_one() in decim_body.h
+        if constexpr (!FRAME) {
+            unsigned *dst = oc.store ? oc.p : oc.dump;
+            *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
+            oc.p += oc.store ? 16 : 0;
+        } else {
+            // UDPSinkFEC::write framing (UDPSinkFEC.cpp:134-155), see store_one() in decim_body.h
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    unsigned w2 = oc.w + r;
-                    size_t f2 = oc.fdw;
-                    if (w2 >= 16129u) { w2 -= 16129u; f2 += oc.frame_dw; }
-                    const unsigned b = w2 / 127u, i = w2 - b * 127u;
-                    oc.p[f2 + (size_t)(1u + b) * 128u + 1u + i] = pk[r];
-                }
+            for (int r = 0; r < 4; ++r) {
+                unsigned w2 = oc.w + r;
+                size_t f2 = oc.fdw;
+                if (w2 >= 16129u) { w2 -= 16129u; f2 += oc.frame_dw; }
+                const unsigned b = w2 / 127u, i = w2 - b * 127u;
+                unsigned *dst = oc.store ? oc.p + (f2 + (size_t)(1u + b) * 128u + 1u + i) : oc.dump + r;
+                *dst = pk[r];
             }
-        }
-        if (oc.store) {
-            if (!oc.frame_mode) {
-                oc.p += 16;
-            } else {
-                oc.w += 16;
-                if (oc.w >= 16129u) { oc.w -= 16129u; oc.fdw += oc.frame_dw; }
-            }
+            oc.w += oc.store ? 16u : 0u;
+            if (oc.w >= 16129u) { oc.w -= 16129u; oc.fdw += oc.frame_dw; }
         }
     }
 }
 
-template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw)
+template <int NS, bool FRAME> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, int *ring)
 {
     constexpr int L = NS;
     constexpr int P = 4 << (NS - 1);    // first-stage steps per period
@@ -216,23 +245,29 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
 
     MfConst k;
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) k.A[m][ph] = *reinterpret_cast<const int4_t *>(&mf_atab.w[m][ph][lane][0]);
     const int b13 = a.bias << 13;
-    const int c0 = (int)(128u * (unsigned)mf_tap_sum()) + b13;
-    k.cin0 = (int4_t){c0, c0, c0, c0};
-    k.cinN = (int4_t){b13, b13, b13, b13};
+    k.cin0 = (int)opaque(128u * (unsigned)mf_tap_sum() + (unsigned)b13); // (opaque: hipcc otherwise splits it into (e + bias) << 13 + c, two ops)
+    k.cinN = b13;
+    {
+        int *col = ring + n * MF_RING_PITCH;
+        k.ring_wr = col + 2 * q;
+        k.ring_rd = col + 4 * q;
+        k.ring_rd4b = col + ((20 + 4 * q) & 31);
+        for (int i = lane; i < NS * MF_RING_STAGE; i += 64) ring[i] = 0;
+    }
 
     MfOut oc;
     oc.store = 0;
+    oc.dump = a.mf_dump + 4 * lane;
     oc.norm = a.norm; oc.trunk = a.trunk;
-    oc.frame_mode = a.frame_mode;
     oc.frame_dw = (size_t)a.frame_blocks * 128u;
     {
         unsigned *obase = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
         const size_t first = ((wave_start + (size_t)p * S) >> L) + 4u * (unsigned)q; // this lane's first output
-        if (!a.frame_mode) {
+        if constexpr (!FRAME) {
             oc.p = obase + first;
             oc.w = 0; oc.fdw = 0;
         } else {
@@ -246,13 +281,14 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
 
     MfState<NS> st;
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+    for (int s = 0; s < NS; ++s) {
 #pragma unroll
-        for (int b = 0; b < 3; ++b) { st.O[s][b] = (int4_t){0, 0, 0, 0}; st.E[s][b] = (int4_t){0, 0, 0, 0}; }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { st.pend[s][0][0] = st.pend[s][0][1] = st.pend[s][1][0] = st.pend[s][1][1] = 0u; }
+        for (int b = 0; b < 3; ++b) st.O[s][b] = (int4_t){0, 0, 0, 0};
+        st.pend[s][0] = st.pend[s][1] = 0u;
+    }
 
     const unsigned selc = comp ? 0x07030602u : 0x05010400u;
+    const int esh = comp ? 16 : 0;
     uint4_t ld[D][2];
     auto issue = [&](int slot, int g) {
         const char *src = wbase + (size_t)g * 128u + loff;
@@ -274,24 +310,25 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
                 g = g < T ? g : T - 1;
                 issue(slot, g);
             }
-            // raw samples 4q .. 4q+3 (r0) and 16 + 4q .. (r1) of the step's 32: x, z even; y, w odd
+            // raw samples 4q .. 4q+3 (r0) and 16 + 4q .. (r1) of the step's 32: x, z even; y, w odd.
+            // even ones: entries 2q, 2q+1 and 8 + 2q, 8 + 2q+1 of block i of the first stage's even plane
+            int *wr = k.ring_wr + 16 * (i & 1);
+            *reinterpret_cast<int2_t *>(wr) = (int2_t){sbfe16(r0.x, esh), sbfe16(r0.z, esh)};
+            *reinterpret_cast<int2_t *>(wr + 8) = (int2_t){sbfe16(r1.x, esh), sbfe16(r1.z, esh)};
             const unsigned ao = perm(r0.w, r0.y, selc), bo = perm(r1.w, r1.y, selc);
-            const unsigned ae = perm(r0.z, r0.x, selc), be = perm(r1.z, r1.x, selc);
-            const unsigned X = 0x80808080u;
-            st.O[0][0][i & 3] = (int)(perm(bo, ao, 0x05040100u) ^ X);
+            st.O[0][0][i & 3] = (int)(perm(bo, ao, 0x05040100u) ^ 0x80808080u);
             st.O[0][1][i & 3] = (int)perm(bo, ao, 0x07060302u);
-            st.E[0][0][i & 3] = (int)(perm(be, ae, 0x05040100u) ^ X);
-            st.E[0][1][i & 3] = (int)perm(be, ae, 0x07060302u);
-            mf_stage<NS, 0, i>(st, k, oc, comp);
+            mf_stage<NS, FRAME, 0, i>(st, k, oc, comp);
         });
     }
 }
 
 // grid.x = nstreams * mf_npieces VALU workgroups (head + tail pieces of every stream), then the matrix-core
 // workgroups (four waves = four groups of 8 spans each)
-template <int L, bool PACK16> __global__ __launch_bounds__(NT, 2) void decim_mfma_kernel(DecimArgs a)
+template <int L, bool PACK16, bool FRAME> __global__ __launch_bounds__(NT, 2) void decim_mfma_kernel(DecimArgs a)
 {
-    __shared__ __attribute__((aligned(16))) int lds[DecimLds<L, 2, PACK16>::dwords];
+    constexpr int LDSDW = DecimLds<L, 2, PACK16>::dwords > mf_ring_dwords<L>() ? DecimLds<L, 2, PACK16>::dwords : mf_ring_dwords<L>();
+    __shared__ __attribute__((aligned(16))) int lds[LDSDW];
     const int nleg = a.nstreams * a.mf_npieces;
     const int bx = blockIdx.x;
     if (bx < nleg) {
@@ -308,15 +345,21 @@ template <int L, bool PACK16> __global__ __launch_bounds__(NT, 2) void decim_mfm
     }
     const int gw = __builtin_amdgcn_readfirstlane((bx - nleg) * 4 + (int)(threadIdx.x >> 6));
     if (gw >= a.nstreams * a.mf_wps) return;
-    mf_wave<L>(a, gw);
+    mf_wave<L, FRAME>(a, gw, lds + (threadIdx.x >> 6) * (L * MF_RING_STAGE));
 }
 
 template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream_t stream)
 {
     const int nleg = a.nstreams * a.mf_npieces;
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
-    if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true>), dim3(nleg + nmf), dim3(NT), 0, stream, a);
-    else hipLaunchKernelGGL((decim_mfma_kernel<L, false>), dim3(nleg + nmf), dim3(NT), 0, stream, a);
+    const dim3 grid(nleg + nmf), block(NT);
+    if (a.frame_mode) {
+        if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((decim_mfma_kernel<L, false, true>), grid, block, 0, stream, a);
+    } else {
+        if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((decim_mfma_kernel<L, false, false>), grid, block, 0, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -116,6 +116,7 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
     cm256_karatsuba_leaf_tables(kl.data());
     if (hipMalloc(reinterpret_cast<void **>(&c->enc_leaves), kl.size()) != hipSuccess ||
         hipMemcpy(c->enc_leaves, kl.data(), kl.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "upload encoder constants"); }
+    if (hipMalloc(reinterpret_cast<void **>(&c->decim_dump), 4096) != hipSuccess) { c->decim_dump = nullptr; ctx_free(c); return fail(SDRHIP_ENOMEM, "hipMalloc decimator scratch"); }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { ctx_free(c); return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
     *out = c;
     return SDRHIP_OK;
@@ -146,6 +147,7 @@ static void sdrhip::ctx_free(sdrhip_ctx *c)
     if (c->gf_tab) (void)hipFree(c->gf_tab);
     if (c->enc_matrix) (void)hipFree(c->enc_matrix);
     if (c->enc_leaves) (void)hipFree(c->enc_leaves);
+    if (c->decim_dump) (void)hipFree(c->decim_dump);
     if (c->dec_coef) (void)hipFree(c->dec_coef);
     if (c->dec_dst) (void)hipFree(c->dec_dst);
     c->pin.release();
@@ -330,6 +332,7 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     bool use_mfma = false;
     if (env.path != DECIM_PATH_VALU && (env.path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= env.min_samples))
         use_mfma = plan_decimate_mfma((int)L, fcpos, a.n_used, d->nstreams, env.span, &a);
+    a.mf_dump = c->decim_dump;
     hipError_t e;
     {
         KTimer kt(c, SDRHIP_K_DECIMATE);

@@ -86,6 +86,7 @@ struct sdrhip_ctx {
     uint8_t *gf_tab = nullptr;               // 256 x 32 B multiplier tables (device)
     uint8_t *enc_matrix = nullptr;           // 128 x 128 encode matrix, rows 128..255 (device)
     uint8_t *enc_leaves = nullptr;           // Karatsuba leaf tables of the structured k = 128 encoder (device)
+    unsigned *decim_dump = nullptr;          // sink of the matrix-core decimator's warm-up stores (DecimArgs::mf_dump)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // decode-plan cache: erasure pattern (the 128 received block indices) -> matrix slot on the device
     static constexpr int DEC_SLOTS = 64;

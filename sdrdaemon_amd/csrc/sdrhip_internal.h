@@ -51,6 +51,7 @@ struct DecimArgs {
     // matrix-core waves run mf_wps groups of 8 spans of mf_span raw samples from mf_head on
     size_t mf_head, mf_span, mf_tail_start, mf_tail_seg;
     int mf_wps, mf_npieces;
+    unsigned *mf_dump;   // >= 1 KiB of device memory that swallows the stores of the warm-up period
 };
 
 // returns hipSuccess or the launch error
