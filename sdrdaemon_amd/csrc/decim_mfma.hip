@@ -32,6 +32,10 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef MF_WAVES
+#define MF_WAVES 2
+#endif
+
 namespace sdrhip {
 namespace {
 
@@ -230,7 +234,10 @@ template <int NS, bool FRAME> __device__ __forceinline__ void mf_wave(const Deci
 {
     constexpr int L = NS;
     constexpr int P = 4 << (NS - 1);    // first-stage steps per period
-    constexpr int D = 4;                // steps of loads in flight
+#ifndef MF_DEPTH
+#define MF_DEPTH 4
+#endif
+    constexpr int D = MF_DEPTH;         // steps of loads in flight
     constexpr size_t W = (size_t)64 << L; // warm-up = one period, raw samples
     static_assert(P % D == 0, "prefetch ring");
     const int lane = threadIdx.x & 63;
@@ -290,26 +297,24 @@ template <int NS, bool FRAME> __device__ __forceinline__ void mf_wave(const Deci
     const unsigned selc = comp ? 0x07030602u : 0x05010400u;
     const int esh = comp ? 16 : 0;
     uint4_t ld[D][2];
-    auto issue = [&](int slot, int g) {
-        const char *src = wbase + (size_t)g * 128u + loff;
-        ld[slot][0] = *reinterpret_cast<const uint4_t *>(src);
-        ld[slot][1] = *reinterpret_cast<const uint4_t *>(src + 64);
-    };
+    // step g of this lane's column: 128 bytes at src + 128 g.  No bounds handling: the loads run D steps past the end
+    // of the span, i.e. into the next span or (last span of a stream) the first 32 D samples of the tail that
+    // plan_decimate_mfma() guarantees
+    const char *src = wbase + loff;
 #pragma unroll
-    for (int d = 0; d < D; ++d) issue(d, d < T ? d : T - 1);
+    for (int d = 0; d < D; ++d) {
+        ld[d][0] = *reinterpret_cast<const uint4_t *>(src + 128 * d);
+        ld[d][1] = *reinterpret_cast<const uint4_t *>(src + 128 * d + 64);
+    }
 
     for (int per = 0; per < nper; ++per) {
         oc.store = per > 0;
-        const int g0 = per * P;
         mf_static_for<P>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int slot = i % D;
             const uint4_t r0 = ld[slot][0], r1 = ld[slot][1];
-            {
-                int g = g0 + i + D;
-                g = g < T ? g : T - 1;
-                issue(slot, g);
-            }
+            ld[slot][0] = *reinterpret_cast<const uint4_t *>(src + 128 * (i + D));
+            ld[slot][1] = *reinterpret_cast<const uint4_t *>(src + 128 * (i + D) + 64);
             // raw samples 4q .. 4q+3 (r0) and 16 + 4q .. (r1) of the step's 32: x, z even; y, w odd.
             // even ones: entries 2q, 2q+1 and 8 + 2q, 8 + 2q+1 of block i of the first stage's even plane
             int *wr = k.ring_wr + 16 * (i & 1);
@@ -320,12 +325,13 @@ template <int NS, bool FRAME> __device__ __forceinline__ void mf_wave(const Deci
             st.O[0][1][i & 3] = (int)perm(bo, ao, 0x07060302u);
             mf_stage<NS, FRAME, 0, i>(st, k, oc, comp);
         });
+        src += 128 * P;
     }
 }
 
 // grid.x = nstreams * mf_npieces VALU workgroups (head + tail pieces of every stream), then the matrix-core
 // workgroups (four waves = four groups of 8 spans each)
-template <int L, bool PACK16, bool FRAME> __global__ __launch_bounds__(NT, 2) void decim_mfma_kernel(DecimArgs a)
+template <int L, bool PACK16, bool FRAME> __global__ __launch_bounds__(NT, MF_WAVES) void decim_mfma_kernel(DecimArgs a)
 {
     constexpr int LDSDW = DecimLds<L, 2, PACK16>::dwords > mf_ring_dwords<L>() ? DecimLds<L, 2, PACK16>::dwords : mf_ring_dwords<L>();
     __shared__ __attribute__((aligned(16))) int lds[LDSDW];
@@ -376,15 +382,21 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
     if (span_override) {
         S = (span_override + W - 1) / W * W;
     } else {
-        // one round of 2 waves per SIMD (2048 waves of 8 spans) when the call is big enough; longer spans beyond
-        S = (n * (size_t)nstreams / (2048 * 8)) / W * W;
-        if (S < 16 * W) S = 16 * W;               // warm-up <= 6 %
+        // one round of three waves per SIMD (the kernel's 160 VGPRs admit three 4-wave workgroups per CU; the VALU
+        // pieces take a few of the 768 slots): ~2900 waves of 8 spans when the call is big enough, longer spans
+        // beyond; at least 8 warm-ups per span (<= 12 % overhead)
+        S = (n * (size_t)nstreams / (2900 * 8) + W - 1) / W * W;
+        if (S < 8 * W) S = 8 * W;
         if (S > 256 * W) S = 256 * W;
     }
-    const size_t wps = n / (8 * S);
+    size_t wps = n / (8 * S);
     if (wps == 0 || wps > 0x7fffffffu / (size_t)nstreams) return false;
     if (8 * S * 4 >= 0xffffffffu) return false;   // lane offsets inside a wave are 32 bits
-    const size_t tail_start = head + wps * 8 * S;
+    size_t tail_start = head + wps * 8 * S;
+    if (n_used - tail_start < 256) { // the waves read up to 256 samples past their last span (prefetch)
+        if (--wps == 0) return false;
+        tail_start = head + wps * 8 * S;
+    }
     const size_t tail = n_used - tail_start;
     const size_t seg = 16384;                     // 8 passes of the VALU code per tail piece
     size_t ntail = (tail + seg - 1) / seg;
