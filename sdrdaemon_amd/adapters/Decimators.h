@@ -5,6 +5,8 @@
 #ifndef INCLUDE_DECIMATORS_H_
 #define INCLUDE_DECIMATORS_H_
 
+#include <mutex>
+
 #include "sdrhip_adapter_common.h"
 
 class Decimators
@@ -55,11 +57,20 @@ private:
         sampleSize = ss;
     }
     void run(int log2, int fcpos, unsigned int& sampleSize, const IQSampleVector& in, IQSampleVector& out) { call(handle(), log2, fcpos, sampleSize, in, out); }
+    static sdrhip_decimators *staticHandle()
+    {
+        sdrhip_decimators *h = nullptr;
+        sdrhip_adapter::check(sdrhip_decimators_create(sdrhip_adapter::context(), 1, sdrhip_adapter::hb_variant(), &h), "sdrhip_decimators_create");
+        return h;
+    }
     static void staticRun(int log2, int fcpos, unsigned int& sampleSize, const IQSampleVector& in, IQSampleVector& out)
     {
-        // the filter-less entry points are static in the reference (Decimators.h:35-39): a shared handle serves them
-        static sdrhip_decimators *h = nullptr;
-        if (!h) sdrhip_adapter::check(sdrhip_decimators_create(sdrhip_adapter::context(), 1, sdrhip_adapter::hb_variant(), &h), "sdrhip_decimators_create");
+        // the filter-less entry points are static in the reference (Decimators.h:35-39) and callable from any thread:
+        // one shared handle serves them (created once: thread-safe static initialisation), a mutex makes the calls on
+        // it single-threaded as the library asks of a handle (they carry no filter state)
+        static sdrhip_decimators *h = staticHandle();
+        static std::mutex mtx;
+        std::lock_guard<std::mutex> guard(mtx);
         call(h, log2, fcpos, sampleSize, in, out);
     }
 };

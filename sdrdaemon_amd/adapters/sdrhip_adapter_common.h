@@ -48,13 +48,21 @@ inline void check(int rc, const char *what)
     if (rc != SDRHIP_OK) throw std::runtime_error(std::string(what) + ": " + sdrhip_last_error());
 }
 
+inline sdrhip_ctx *new_context()
+{
+    sdrhip_ctx *ctx = nullptr;
+    const char *dev = std::getenv("SDRHIP_DEVICE");
+    check(sdrhip_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx), "sdrhip_ctx_create");
+    return ctx;
+}
+
+// The process-wide context of the DSP adapters (Decimators, Interpolators): created once (C++11 guarantees that the
+// initialisation of a function-local static is thread-safe), lives for the process like the reference's static filter
+// tables.  The library serialises the calls made on one context, so objects that are driven from ANOTHER thread
+// (CM256 inside the reference's transmit / receive threads) take a context of their own instead: new_context().
 inline sdrhip_ctx *context()
 {
-    static sdrhip_ctx *ctx = nullptr; // lives for the process (like the reference's static filter tables)
-    if (!ctx) {
-        const char *dev = std::getenv("SDRHIP_DEVICE");
-        check(sdrhip_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx), "sdrhip_ctx_create");
-    }
+    static sdrhip_ctx *ctx = new_context();
     return ctx;
 }
 

@@ -90,6 +90,14 @@ extern "C" int sdrhip_device_count(void)
 
 namespace sdrhip {
 static void ctx_free(sdrhip_ctx *c);
+static void drop_kernel_events(sdrhip_ctx *c)
+{
+    (void)hipStreamSynchronize(c->stream);
+    for (int k = 0; k < 4; ++k) {
+        for (auto &pr : c->kev[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+        c->kev[k].clear();
+    }
+}
 }
 
 extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
@@ -123,10 +131,10 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
 }
 
 namespace sdrhip {
-void ctx_retain(sdrhip_ctx *c) { ++c->refs; }
+void ctx_retain(sdrhip_ctx *c) { c->refs.fetch_add(1); }
 void ctx_release(sdrhip_ctx *c)
 {
-    if (--c->refs == 0 && c->dying) ctx_free(c);
+    if (c->refs.fetch_sub(1) == 1 && c->dying) ctx_free(c);
 }
 } // namespace sdrhip
 
@@ -136,13 +144,14 @@ extern "C" void sdrhip_ctx_destroy(sdrhip_ctx *c)
 {
     if (!c || c->dying) return;
     c->dying = true;
-    if (c->refs == 0) ctx_free(c);
+    if (c->refs.load() == 0) ctx_free(c);
 }
 
 static void sdrhip::ctx_free(sdrhip_ctx *c)
 {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    drop_kernel_events(c);
     c->in.release(); c->out.release(); c->aux.release(); c->aux3.release();
     if (c->gf_tab) (void)hipFree(c->gf_tab);
     if (c->enc_matrix) (void)hipFree(c->enc_matrix);
@@ -159,6 +168,7 @@ static void sdrhip::ctx_free(sdrhip_ctx *c)
 extern "C" int sdrhip_ctx_synchronize(sdrhip_ctx *c)
 {
     if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
+    sdrhip::CtxLock lock_(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SDRHIP_OK;
 }
@@ -182,13 +192,16 @@ extern "C" int sdrhip_ctx_timing_end(sdrhip_ctx *c, float *ms)
 extern "C" int sdrhip_ctx_kernel_timing(sdrhip_ctx *c, int enable)
 {
     if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
+    sdrhip::CtxLock lock_(c);
     c->ktime_on = enable != 0;
+    if (!enable) drop_kernel_events(c); // pairs nobody read
     return SDRHIP_OK;
 }
 
 extern "C" int sdrhip_ctx_kernel_timing_read(sdrhip_ctx *c, int cls, double *total_ms, unsigned *launches)
 {
     if (!c || cls < 0 || cls > 3 || !total_ms || !launches) return fail(SDRHIP_EINVAL, "kernel_timing_read: bad argument");
+    sdrhip::CtxLock lock_(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     double sum = 0;
     unsigned n = 0;
@@ -249,6 +262,7 @@ extern "C" void sdrhip_decimators_destroy(sdrhip_decimators *d)
 extern "C" int sdrhip_decimators_reset(sdrhip_decimators *d)
 {
     if (!d) return fail(SDRHIP_EINVAL, "decimators is NULL");
+    sdrhip::CtxLock lock_(d->ctx);
     size_t bytes = (size_t)d->nstreams * DEC_STATE_WORDS * sizeof(int32_t);
     HIP_TRY(hipMemsetAsync(d->state[0], 0, bytes, d->ctx->stream)); // ctor zero fill, EO1.h:171-188
     HIP_TRY(hipMemsetAsync(d->state[1], 0, bytes, d->ctx->stream));
@@ -352,6 +366,7 @@ extern "C" int sdrhip_decimate(sdrhip_decimators *d, int log2decim, int fcpos, u
                                size_t n_in, size_t in_stride, int16_t *iq_out, size_t out_stride, size_t *n_out, int mem)
 {
     if (!d || !sampleSize) return fail(SDRHIP_EINVAL, "decimate: NULL handle or sampleSize");
+    sdrhip::CtxLock lock_(d->ctx);
     if (log2decim < 0 || log2decim > 6) return fail(SDRHIP_EINVAL, "Invalid log2 decimation factor"); // Downsampler.cpp:39-43
     if (fcpos < SDRHIP_FC_INF || fcpos > SDRHIP_FC_CEN) return fail(SDRHIP_EINVAL, "Invalid Fc position index"); // :55-59
     if (*sampleSize < 1 || *sampleSize > 16) return fail(SDRHIP_EINVAL, "sampleSize must be 1..16");

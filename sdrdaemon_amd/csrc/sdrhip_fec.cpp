@@ -2,6 +2,7 @@
 // host (gf256.cpp), block arithmetic on the GPU (gf_kernels.hip).
 #include "gf256.h"
 #include "sdrhip_host.h"
+#include <iterator>
 
 #include <cstring>
 #include <map>
@@ -135,6 +136,10 @@ static int fec_decode_chunk(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_by
             // the reference passes the number of RECEIVED recovery blocks as RecoveryCount (:176)
             if (cm256_decode_plan(K, n_recovery, idx, &n_rec, rec_pos.data(), erased.data(), coef.data())) {
                 c->dec_free.push_back(slot);
+                // undecodable patterns (e.g. duplicated datagrams) are remembered too, but not for ever: a receiver fed
+                // from the network must not grow by one key per bad pattern
+                if (c->dec_slot_of.size() > 4 * (size_t)SLOTS)
+                    for (auto jt = c->dec_slot_of.begin(); jt != c->dec_slot_of.end();) jt = jt->second < 0 ? c->dec_slot_of.erase(jt) : std::next(jt);
                 c->dec_slot_of[key] = -1; // "CM256 decode error" (:199): the frame keeps what was received
                 holes.push_back(f);
                 continue;
@@ -269,6 +274,7 @@ extern "C" int sdrhip_fec_encode_frames(sdrhip_ctx *c, const uint8_t *frames, si
                                         int mem)
 {
     if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
+    sdrhip::CtxLock lock_(c);
     if (nb_fec < 0 || nb_fec > 128) return fail(SDRHIP_EINVAL, "nb_fec must be 0..128 (OriginalCount + RecoveryCount <= 256)");
     if (nframes == 0 || nb_fec == 0) return SDRHIP_OK;
     if (!frames || !recovery_out) return fail(SDRHIP_EINVAL, "fec_encode_frames: NULL buffer");
@@ -290,6 +296,7 @@ extern "C" int sdrhip_fec_decode_frames(sdrhip_ctx *c, const uint8_t *rx, const 
                                         uint8_t *block0_out, int mem)
 {
     if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
+    sdrhip::CtxLock lock_(c);
     if (nframes == 0) return SDRHIP_OK;
     if (!rx || !payload_out) return fail(SDRHIP_EINVAL, "fec_decode_frames: NULL buffer");
     HIP_TRY(hipSetDevice(c->device));
@@ -322,6 +329,7 @@ extern "C" int sdrhip_fec_decode_frames(sdrhip_ctx *c, const uint8_t *rx, const 
 extern "C" int sdrhip_cm256_encode(sdrhip_ctx *c, sdrhip_cm256_params p, const sdrhip_cm256_block *originals, void *recoveryBlocks)
 {
     if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
+    sdrhip::CtxLock lock_(c);
     if (p.OriginalCount <= 0 || p.RecoveryCount <= 0 || p.BlockBytes <= 0) return fail(-1, "cm256_encode: invalid params"); // upstream -1
     if (p.OriginalCount + p.RecoveryCount > 256) return fail(-2, "cm256_encode: OriginalCount + RecoveryCount > 256");      // upstream -2
     if (!originals || !recoveryBlocks) return fail(-3, "cm256_encode: NULL pointer");                                         // upstream -3
@@ -368,6 +376,7 @@ extern "C" int sdrhip_cm256_encode(sdrhip_ctx *c, sdrhip_cm256_params p, const s
 extern "C" int sdrhip_cm256_decode(sdrhip_ctx *c, sdrhip_cm256_params p, sdrhip_cm256_block *blocks)
 {
     if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
+    sdrhip::CtxLock lock_(c);
     if (p.OriginalCount <= 0 || p.RecoveryCount <= 0 || p.BlockBytes <= 0) return fail(-1, "cm256_decode: invalid params");
     if (p.OriginalCount + p.RecoveryCount > 256) return fail(-2, "cm256_decode: OriginalCount + RecoveryCount > 256");
     if (!blocks) return fail(-3, "cm256_decode: NULL pointer");

@@ -4,7 +4,9 @@
 #include "sdrhip_internal.h"
 
 #include <cstdint>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -78,9 +80,13 @@ int fec_decode_device(sdrhip_ctx *ctx, const uint8_t *rx, size_t rx_frame_bytes,
 } // namespace sdrhip
 
 struct sdrhip_ctx {
+    // Every public entry point that works on this context (directly or through one of its handles) holds this lock
+    // for its duration: the staging buffers, the decode-plan cache and the timing log are per context.  Calls on
+    // one context therefore serialise; threads that want to overlap use one context each.
+    std::recursive_mutex mtx;
     int device = 0;
     hipStream_t stream = nullptr;
-    int refs = 0;       // handles created on this context (they keep it alive)
+    std::atomic<int> refs{0}; // handles created on this context (they keep it alive)
     bool dying = false; // sdrhip_ctx_destroy was called while handles were still alive
     sdrhip::DevBuf in, out, aux, aux3;       // staging for SDRHIP_MEM_HOST calls and FEC work areas
     uint8_t *gf_tab = nullptr;               // 256 x 32 B multiplier tables (device)
@@ -103,6 +109,10 @@ struct sdrhip_ctx {
 };
 
 namespace sdrhip {
+struct CtxLock {
+    std::lock_guard<std::recursive_mutex> g;
+    explicit CtxLock(sdrhip_ctx *c) : g(c->mtx) {}
+};
 // RAII: brackets the launches of one kernel class with events when timing is enabled
 struct KTimer {
     sdrhip_ctx *c;
@@ -112,7 +122,8 @@ struct KTimer {
     {
         if (!c->ktime_on) return;
         hipEvent_t e0 = nullptr;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
+        if (hipEventCreate(&e0) != hipSuccess) return;
+        if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); e1 = nullptr; return; }
         (void)hipEventRecord(e0, c->stream);
         c->kev[cls].push_back(std::make_pair(e0, e1));
     }

@@ -50,6 +50,7 @@ extern "C" void sdrhip_interpolators_destroy(sdrhip_interpolators *p)
 extern "C" int sdrhip_interpolators_reset(sdrhip_interpolators *p)
 {
     if (!p) return fail(SDRHIP_EINVAL, "interpolators is NULL");
+    sdrhip::CtxLock lock_(p->ctx);
     size_t bytes = (size_t)p->nstreams * INT_STATE_WORDS * sizeof(int32_t);
     HIP_TRY(hipMemsetAsync(p->state[0], 0, bytes, p->ctx->stream));
     HIP_TRY(hipMemsetAsync(p->state[1], 0, bytes, p->ctx->stream));
@@ -89,6 +90,7 @@ extern "C" int sdrhip_interpolate(sdrhip_interpolators *p, int log2interp, const
                                   int16_t *iq_out, size_t out_stride, size_t *n_out, int mem)
 {
     if (!p) return fail(SDRHIP_EINVAL, "interpolate: NULL handle");
+    sdrhip::CtxLock lock_(p->ctx);
     if (log2interp < 0 || log2interp > 6) return fail(SDRHIP_EINVAL, "Invalid log2 interpolation factor"); // Upsampler.cpp:38-42
     if (n_in && (!iq_in || !iq_out)) return fail(SDRHIP_EINVAL, "interpolate: NULL buffer");
     sdrhip_ctx *c = p->ctx;
@@ -170,6 +172,7 @@ static int rx_check_config(const sdrhip_rx_config *cfg)
 extern "C" int sdrhip_rx_reconfigure(sdrhip_rx *rx, const sdrhip_rx_config *cfg)
 {
     if (!rx || !cfg) return fail(SDRHIP_EINVAL, "rx_reconfigure: NULL argument");
+    sdrhip::CtxLock lock_(rx->ctx);
     int rc = rx_check_config(cfg);
     if (rc) return rc;
     if (cfg->hb_variant != rx->cfg.hb_variant) return fail(SDRHIP_EINVAL, "rx_reconfigure: hb_variant is fixed at creation");
@@ -225,6 +228,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
                                  uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames, int mem)
 {
     if (!rx) return fail(SDRHIP_EINVAL, "rx is NULL");
+    sdrhip::CtxLock lock_(rx->ctx);
     if (n_frames) *n_frames = 0;
     if (n_in == 0) return SDRHIP_OK;
     if (!iq_in) return fail(SDRHIP_EINVAL, "rx_process: NULL input");
@@ -381,6 +385,7 @@ extern "C" int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t
                                  int16_t *iq_out, size_t out_stride, size_t *n_out, int mem)
 {
     if (!tx) return fail(SDRHIP_EINVAL, "tx is NULL");
+    sdrhip::CtxLock lock_(tx->ctx);
     const size_t n_payload = nframes * SDRHIP_SAMPLES_PER_FRAME;
     const size_t n_res = n_payload << tx->log2interp;
     if (n_out) *n_out = n_res;

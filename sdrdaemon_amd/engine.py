@@ -370,6 +370,7 @@ class RxPipe:
         self.cfg = RxConfig(log2decim, fcpos, hb_variant, sample_bits, nb_fec, center_frequency_khz, sample_rate)
         self.h = C.c_void_p()
         self.m_error = ""
+        self.m_device_rate = sample_rate << log2decim  # DeviceSource::get_sample_rate(): the sink gets it >> decim
         check(ctx.lib.sdrhip_rx_create(ctx.h, nstreams, C.byref(self.cfg), C.byref(self.h)))
 
     def error(self):
@@ -404,7 +405,10 @@ class RxPipe:
             if "freq" in m:
                 kw["center_frequency_khz"] = int(m["freq"]) // 1000
             if "srate" in m:
-                kw["sample_rate"] = int(m["srate"]) >> kw.get("log2decim", self.cfg.log2decim)
+                self.m_device_rate = int(m["srate"])
+            if "srate" in m or "decim" in m:
+                # the reference recomputes get_sample_rate() / (1 << decim) for every block (sdrdaemonrx.cpp:640-644)
+                kw["sample_rate"] = self.m_device_rate >> kw.get("log2decim", self.cfg.log2decim)
             if kw:
                 self.reconfigure(**kw)
         except (ValueError, SdrHipError) as e:

@@ -6,6 +6,7 @@
 //   adapter_test in.bin dec.bin int.bin fec.bin
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "Decimators.h"
@@ -26,6 +27,11 @@ static std::vector<IQSample> read_iq(const char *path)
     if (std::fread(v.data(), 4, v.size(), f) != v.size()) v.clear();
     std::fclose(f);
     return v;
+}
+
+static bool differ(const IQSampleVector &x, const IQSampleVector &y)
+{
+    return x.size() != y.size() || std::memcmp(x.data(), y.data(), x.size() * 4) != 0;
 }
 
 static void write_bin(const char *path, const void *p, size_t n)
@@ -128,6 +134,37 @@ int main(int argc, char **argv)
         all.insert(all.end(), s4.begin(), s4.end());
         write_bin(argv[5], all.data(), all.size() * 4);
         std::printf("samplers OK %u\n", s);
+    }
+    // --- threads, the way the reference uses the classes: the main thread decimates (sdrdaemonrx.cpp:640) while
+    // UDPSinkFEC's transmit thread encodes (UDPSinkFEC.cpp:246) and a third thread calls a static entry point
+    {
+        IQSampleVector ref16, ref2;
+        unsigned int s = 16;
+        { Decimators d0; d0.decimate16_cen(s, a, ref16); }
+        s = 16;
+        Decimators::decimate2_inf(s, a, ref2);
+        std::vector<unsigned char> orig(128 * 508), rec_ref(32 * 508);
+        std::memcpy(orig.data(), in.data(), orig.size());
+        CM256::cm256_encoder_params params = {128, 32, 508};
+        std::vector<CM256::cm256_block> blocks(128);
+        for (int i = 0; i < 128; ++i) { blocks[i].Block = orig.data() + i * 508; blocks[i].Index = (unsigned char)i; }
+        { CM256 c0; if (c0.cm256_encode(params, blocks.data(), rec_ref.data())) return 5; }
+        int bad[3] = {0, 0, 0};
+        std::thread t1([&] {
+            for (int r = 0; r < 40; ++r) { Decimators d; IQSampleVector o; unsigned int q = 16; d.decimate16_cen(q, a, o); bad[0] += differ(o, ref16); }
+        });
+        std::thread t2([&] {
+            CM256 cm;
+            std::vector<unsigned char> rec(32 * 508);
+            for (int r = 0; r < 40; ++r) { std::memset(rec.data(), 0, rec.size()); bad[1] += cm.cm256_encode(params, blocks.data(), rec.data()) != 0 || rec != rec_ref; }
+        });
+        std::thread t3([&] {
+            for (int r = 0; r < 40; ++r) { IQSampleVector o; unsigned int q = 16; Decimators::decimate2_inf(q, a, o); bad[2] += differ(o, ref2); }
+        });
+        for (int r = 0; r < 40; ++r) { IQSampleVector o; unsigned int q = 16; Decimators::decimate2_inf(q, a, o); bad[2] += differ(o, ref2); }
+        t1.join(); t2.join(); t3.join();
+        if (bad[0] || bad[1] || bad[2]) { std::printf("threads FAILED %d %d %d\n", bad[0], bad[1], bad[2]); return 6; }
+        std::printf("threads OK\n");
     }
     return 0;
 }

@@ -33,7 +33,7 @@ def test_adapters_run_like_the_reference_call_sites(tmp_path, oracle):
     g.build()
     exe = str(tmp_path / "adapter_test")
     libdir = os.path.join(ROOT, "sdrdaemon_amd")
-    subprocess.run(["g++", "-std=c++11", "-O1"] + INC + [SRC, "-L", libdir, "-lsdrhip", "-Wl,-rpath," + libdir, "-o", exe],
+    subprocess.run(["g++", "-std=c++11", "-O1", "-pthread"] + INC + [SRC, "-L", libdir, "-lsdrhip", "-Wl,-rpath," + libdir, "-o", exe],
                    check=True)
     x = signals.mixed(2 * 65536, 9)
     fin = str(tmp_path / "in.bin")
@@ -43,6 +43,7 @@ def test_adapters_run_like_the_reference_call_sites(tmp_path, oracle):
     r = subprocess.run([exe, fin] + outs, capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "sampleSize 16 14" in r.stdout and "fec roundtrip OK" in r.stdout, r.stdout
+    assert "threads OK" in r.stdout, r.stdout  # main-thread decimation, transmit-thread CM256, static entry points: concurrently
     od = oracle.decimators(0)
     a, _ = od.decimate(4, 2, 16, x[:65536])
     b, _ = od.decimate(4, 2, 16, x[65536:])

@@ -248,12 +248,16 @@ def test_rx_pipe_live_reconfiguration(ctx, oracle):
     assert not rx.configure({"decim": "9"}) and "decimation" in rx.error()   # rejected, nothing changes
     assert not rx.configure({"fecblk": "200"})
     total = 0
+    dev_rate = 625000 << 4  # DeviceSource::get_sample_rate(); the sink is told dev_rate / 2^decim (sdrdaemonrx.cpp:640-644)
     for i, (msg, log2, fcpos, R, nd) in enumerate(steps):
         assert rx.configure(msg), rx.error()
+        if "srate" in msg:
+            dev_rate = int(msg["srate"])
         for fr in frs:
             fr.s.nb_fec_blocks = R
+            fr.s.sample_rate = dev_rate >> log2
             if "freq" in msg:
-                fr.s.center_frequency_khz, fr.s.sample_rate = 144800, 2000000 >> log2
+                fr.s.center_frequency_khz = 144800
         x = np.stack([signals.noise(nd << log2, 300 + 10 * i + s) for s in range(S)])
         got = rx.process(x, tv_sec=50 + i, tv_usec=i)
         assert got.shape[2] == 128 + R
