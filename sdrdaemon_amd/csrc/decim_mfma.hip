@@ -114,13 +114,10 @@ struct MfConst {
 };
 
 struct MfOut {
-    unsigned *p;          // plain mode: where this lane's next four outputs go; frame mode: stream's frame area
+    unsigned *p;          // where this lane's next four outputs go
     unsigned *dump;       // 16 bytes per lane that swallow the stores of the warm-up period (no branch in the loop body)
     int store;            // 0 during warm-up
     int norm, trunk;
-    unsigned w;           // frame mode: position of the lane's next output inside its frame (0..16128)
-    size_t fdw;           // frame mode: dword offset of that frame
-    size_t frame_dw;      // dwords per frame slot
 };
 
 __device__ __forceinline__ int sbfe16(unsigned v, int off) { return (int)__builtin_amdgcn_sbfe((int)v, (unsigned)off, 16u); }
@@ -158,7 +155,7 @@ template <int S, int I> __device__ __forceinline__ int4_t mf_centre(const MfCons
     return r;
 }
 
-template <int NS, bool FRAME, int S, int I> __device__ __forceinline__ void mf_stage(MfState<NS> &st, const MfConst &k, MfOut &oc, int comp)
+template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState<NS> &st, const MfConst &k, MfOut &oc, int comp)
 {
     constexpr int PH = I & 3;
     const int4_t Ah0 = k.A[0][PH], Ah1 = k.A[1][PH];
@@ -197,7 +194,7 @@ template <int NS, bool FRAME, int S, int I> __device__ __forceinline__ void mf_s
             st.O[S + 1][0][NJ] = (int)(perm(po, st.pend[S + 1][0], 0x05040100u) ^ X);
             st.O[S + 1][1][NJ] = (int)(perm(po, st.pend[S + 1][0], 0x07060302u) ^ X);
             st.O[S + 1][2][NJ] = (int)(perm(po2, st.pend[S + 1][1], 0x05040100u) ^ X);
-            mf_stage<NS, FRAME, S + 1, (I >> 1)>(st, k, oc, comp);
+            mf_stage<NS, S + 1, (I >> 1)>(st, k, oc, comp);
         }
     } else {
         // lanes n = 2p (I) and 2p + 1 (Q) hold the same outputs: both pack the same dwords and store them to the
@@ -209,28 +206,13 @@ template <int NS, bool FRAME, int S, int I> __device__ __forceinline__ void mf_s
             const int other = __builtin_amdgcn_update_dpp(0, o[r], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
             pk[r] = final_pack(comp ? other : o[r], comp ? o[r] : other, oc.norm, oc.trunk);
         }
-        if constexpr (!FRAME) {
-            unsigned *dst = oc.store ? oc.p : oc.dump;
-            *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
-            oc.p += oc.store ? 16 : 0;
-        } else {
-            // UDPSinkFEC::write framing (UDPSinkFEC.cpp:134-155), see store_one() in decim_body.h
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                unsigned w2 = oc.w + r;
-                size_t f2 = oc.fdw;
-                if (w2 >= 16129u) { w2 -= 16129u; f2 += oc.frame_dw; }
-                const unsigned b = w2 / 127u, i = w2 - b * 127u;
-                unsigned *dst = oc.store ? oc.p + (f2 + (size_t)(1u + b) * 128u + 1u + i) : oc.dump + r;
-                *dst = pk[r];
-            }
-            oc.w += oc.store ? 16u : 0u;
-            if (oc.w >= 16129u) { oc.w -= 16129u; oc.fdw += oc.frame_dw; }
-        }
+        unsigned *dst = oc.store ? oc.p : oc.dump;
+        *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
+        oc.p += oc.store ? 16 : 0;
     }
 }
 
-template <int NS, bool FRAME> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, int *ring)
+template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, int *ring)
 {
     constexpr int L = NS;
     constexpr int P = 4 << (NS - 1);    // first-stage steps per period
@@ -270,20 +252,10 @@ template <int NS, bool FRAME> __device__ __forceinline__ void mf_wave(const Deci
     oc.store = 0;
     oc.dump = a.mf_dump + 4 * lane;
     oc.norm = a.norm; oc.trunk = a.trunk;
-    oc.frame_dw = (size_t)a.frame_blocks * 128u;
     {
         unsigned *obase = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
         const size_t first = ((wave_start + (size_t)p * S) >> L) + 4u * (unsigned)q; // this lane's first output
-        if constexpr (!FRAME) {
-            oc.p = obase + first;
-            oc.w = 0; oc.fdw = 0;
-        } else {
-            const uint64_t g = a.frame_sample_base + first;
-            const uint64_t f = g / 16129u;
-            oc.p = obase;
-            oc.w = (unsigned)(g - f * 16129u);
-            oc.fdw = (size_t)f * oc.frame_dw;
-        }
+        oc.p = obase + first;
     }
 
     MfState<NS> st;
@@ -323,7 +295,7 @@ template <int NS, bool FRAME> __device__ __forceinline__ void mf_wave(const Deci
             const unsigned ao = perm(r0.w, r0.y, selc), bo = perm(r1.w, r1.y, selc);
             st.O[0][0][i & 3] = (int)(perm(bo, ao, 0x05040100u) ^ 0x80808080u);
             st.O[0][1][i & 3] = (int)perm(bo, ao, 0x07060302u);
-            mf_stage<NS, FRAME, 0, i>(st, k, oc, comp);
+            mf_stage<NS, 0, i>(st, k, oc, comp);
         });
         src += 128 * P;
     }
@@ -331,7 +303,7 @@ template <int NS, bool FRAME> __device__ __forceinline__ void mf_wave(const Deci
 
 // grid.x = nstreams * mf_npieces VALU workgroups (head + tail pieces of every stream), then the matrix-core
 // workgroups (four waves = four groups of 8 spans each)
-template <int L, bool PACK16, bool FRAME> __global__ __launch_bounds__(NT, MF_WAVES) void decim_mfma_kernel(DecimArgs a)
+template <int L, bool PACK16> __global__ __launch_bounds__(NT, MF_WAVES) void decim_mfma_kernel(DecimArgs a)
 {
     constexpr int LDSDW = DecimLds<L, 2, PACK16>::dwords > mf_ring_dwords<L>() ? DecimLds<L, 2, PACK16>::dwords : mf_ring_dwords<L>();
     __shared__ __attribute__((aligned(16))) int lds[LDSDW];
@@ -351,7 +323,7 @@ template <int L, bool PACK16, bool FRAME> __global__ __launch_bounds__(NT, MF_WA
     }
     const int gw = __builtin_amdgcn_readfirstlane((bx - nleg) * 4 + (int)(threadIdx.x >> 6));
     if (gw >= a.nstreams * a.mf_wps) return;
-    mf_wave<L, FRAME>(a, gw, lds + (threadIdx.x >> 6) * (L * MF_RING_STAGE));
+    mf_wave<L>(a, gw, lds + (threadIdx.x >> 6) * (L * MF_RING_STAGE));
 }
 
 template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream_t stream)
@@ -359,13 +331,8 @@ template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream
     const int nleg = a.nstreams * a.mf_npieces;
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
     const dim3 grid(nleg + nmf), block(NT);
-    if (a.frame_mode) {
-        if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((decim_mfma_kernel<L, false, true>), grid, block, 0, stream, a);
-    } else {
-        if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true, false>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((decim_mfma_kernel<L, false, false>), grid, block, 0, stream, a);
-    }
+    if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((decim_mfma_kernel<L, false>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 

@@ -344,7 +344,7 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     // SDRHIP_DECIM_PATH = valu | mfma | auto (default), SDRHIP_MFMA_SPAN = span length in samples (tests)
     const DecimPathEnv env = decim_path_env(); // (read per call: tests switch paths inside one process)
     bool use_mfma = false;
-    if (env.path != DECIM_PATH_VALU && (env.path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= env.min_samples))
+    if (!frame_mode && env.path != DECIM_PATH_VALU && (env.path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= env.min_samples))
         use_mfma = plan_decimate_mfma((int)L, fcpos, a.n_used, d->nstreams, env.span, &a);
     a.mf_dump = c->decim_dump;
     hipError_t e;
@@ -359,6 +359,19 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     // cannot represent
     d->stage0_int16 = cen && (a.n_used >= (size_t)2 * DEC_HIST || d->stage0_int16);
     return SDRHIP_OK;
+}
+} // namespace sdrhip
+
+namespace sdrhip {
+// would a plain (stream-order) decimate call of this size run on the matrix cores?  (The Rx pipe then decimates into
+// a stream-order buffer and frames it with K2 instead of using the VALU kernel's fused frame epilogue.)
+bool decimate_mfma_applies(const sdrhip_decimators *d, int log2decim, int fcpos, size_t n_in)
+{
+    const DecimPathEnv env = decim_path_env();
+    const size_t n_used = (n_in >> log2decim) << log2decim;
+    if (env.path == DECIM_PATH_VALU || (env.path != DECIM_PATH_MFMA && n_used * (size_t)d->nstreams < env.min_samples)) return false;
+    DecimArgs tmp;
+    return plan_decimate_mfma(log2decim, fcpos, n_used, d->nstreams, env.span, &tmp);
 }
 } // namespace sdrhip
 

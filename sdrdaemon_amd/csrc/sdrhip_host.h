@@ -66,6 +66,7 @@ inline unsigned decimated_sample_size(unsigned log2decim, unsigned ss)
 int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in, size_t n_in,
                     size_t in_stride, int16_t *out, size_t out_stride, size_t *n_out, int frame_mode, int frame_blocks,
                     uint64_t frame_sample_base, const RxMeta *meta = nullptr);
+bool decimate_mfma_applies(const sdrhip_decimators *d, int log2decim, int fcpos, size_t n_in);
 int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *in, size_t n_in, size_t in_stride, int16_t *out,
                        size_t out_stride, size_t *n_out);
 // frames/recovery on the device; recovery slots may be interleaved with the frames

@@ -69,6 +69,20 @@ hipError_t launch_decimate_simple(int log2decim, int fcpos, const int16_t *in, s
                                   size_t out_stride, size_t n_in, int nstreams, int norm, int trunk,
                                   hipStream_t stream);
 
+// K2 (frame_kernels.hip): stream-order samples -> super blocks of the frame area
+struct FrameArgs {
+    const unsigned *in;   // [nstreams][in_stride] IQ dwords
+    unsigned *out;        // frame area: stream s at out + s * out_stride dwords, slot 0 = the frame being filled
+    size_t in_stride, out_stride;
+    size_t n;             // samples per stream in this call
+    uint64_t frame_sample_base; // samples already in slot 0
+    int frame_blocks;     // super blocks per frame slot (128 + nb_fec)
+    int meta_first, meta_count; // as DecimArgs::meta_*
+    unsigned meta_frame_count0;
+    unsigned meta_w[6];
+};
+hipError_t launch_frame_pack(const FrameArgs &a, int nstreams, hipStream_t stream);
+
 struct InterpArgs {
     const int16_t *in;
     int16_t *out;

@@ -134,6 +134,7 @@ struct sdrhip_rx {
     uint16_t frame_count;     // its m_frameCount
     size_t view_slot = 0;     // finished frames of the last call: slots view_slot .. view_slot + view_frames
     size_t view_frames = 0;
+    DevBuf lin;               // stream-order decimator output of a call that is framed by K2
     DevBuf flist;             // frame list of the encode launch (device), relative to the window
     std::vector<int32_t> flist_host;
     size_t flist_done = 0, flist_cap = 0;
@@ -164,8 +165,6 @@ static int rx_check_config(const sdrhip_rx_config *cfg)
     if (cfg->fcpos < 0 || cfg->fcpos > 2) return fail(SDRHIP_EINVAL, "Invalid Fc position index");
     if (cfg->nb_fec < 0 || cfg->nb_fec > 128) return fail(SDRHIP_EINVAL, "nb_fec must be 0..128");
     if (cfg->sample_bits < 1 || cfg->sample_bits > 16) return fail(SDRHIP_EINVAL, "sample_bits must be 1..16");
-    if (cfg->log2decim == 0 || (cfg->fcpos != SDRHIP_FC_CEN && cfg->log2decim <= 2))
-        return fail(SDRHIP_EINVAL, "rx pipe: the filter-less settings (decim 0, inf/sup 1-2) are not fused; use sdrhip_decimate + sdrhip_fec_encode_frames");
     return SDRHIP_OK;
 }
 
@@ -205,6 +204,7 @@ extern "C" void sdrhip_rx_destroy(sdrhip_rx *rx)
     if (!rx) return;
     sdrhip_decimators_destroy(rx->dec);
     rx->work.release();
+    rx->lin.release();
     rx->flist.release();
     delete rx;
 }
@@ -314,11 +314,29 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         memcpy(meta.w, m, 24);
     }
 
-    // ---- decimate straight into the frame layout
     size_t n_out = 0;
-    rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, reinterpret_cast<int16_t *>(work), stream_bytes / 4, &n_out, 1,
-                         FB, rx->pending_samples, &meta);
-    if (rc) return rc;
+    const bool filterless = L == 0 || (rx->cfg.fcpos != SDRHIP_FC_CEN && L <= 2); // Decimators.cpp:22-91,127-170: no cascade kernel
+    if (filterless || decimate_mfma_applies(rx->dec, L, rx->cfg.fcpos, n_in)) {
+        // ---- decimate in stream order, then K2 lays the samples out as super blocks (+ meta blocks and headers)
+        const size_t lstride = (n_dec + 3) & ~(size_t)3;
+        if ((rc = rx->lin.reserve((size_t)S * lstride * 4 + 16))) return rc;
+        rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, rx->lin.as<int16_t>(), lstride, &n_out, 0, 0, 0, nullptr);
+        if (rc) return rc;
+        FrameArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.in = rx->lin.as<unsigned>(); fa.out = reinterpret_cast<unsigned *>(work);
+        fa.in_stride = lstride; fa.out_stride = stream_bytes / 4;
+        fa.n = n_dec; fa.frame_sample_base = rx->pending_samples; fa.frame_blocks = FB;
+        fa.meta_first = meta.first; fa.meta_count = meta.count; fa.meta_frame_count0 = meta.frame_count0;
+        memcpy(fa.meta_w, meta.w, sizeof(fa.meta_w));
+        hipError_t e = launch_frame_pack(fa, S, c->stream);
+        if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "frame pack launch: %s", hipGetErrorString(e));
+    } else {
+        // ---- decimate straight into the frame layout (VALU cascade kernel with the framing epilogue)
+        rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, reinterpret_cast<int16_t *>(work), stream_bytes / 4, &n_out, 1,
+                             FB, rx->pending_samples, &meta);
+        if (rc) return rc;
+    }
 
     // ---- FEC over the completed frames of every stream, recovery blocks land behind block 127
     if (done && R > 0) {

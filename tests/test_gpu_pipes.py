@@ -78,7 +78,9 @@ def test_interpolator_bank_device_memory(ctx, oracle):
         assert np.array_equal(y[s], oracle.interpolators().interpolate(4, x[s])), s
 
 
-@pytest.mark.parametrize("cfg", [(4, 2, 0, 16, 32), (4, 0, 1, 16, 8), (3, 2, 0, 12, 0), (6, 2, 0, 8, 128), (1, 2, 1, 16, 1)])
+@pytest.mark.parametrize("cfg", [(4, 2, 0, 16, 32), (4, 0, 1, 16, 8), (3, 2, 0, 12, 0), (6, 2, 0, 8, 128), (1, 2, 1, 16, 1),
+                                 # the filter-less settings (sdrdaemonrx.cpp:617-636, Decimators.cpp:22-91,127-170): K2 frames them
+                                 (0, 2, 0, 16, 0), (0, 0, 0, 12, 32), (1, 0, 0, 16, 8), (1, 1, 1, 12, 8), (2, 0, 0, 16, 32), (2, 1, 0, 8, 4)])
 def test_rx_pipe_matches_reference_chain(ctx, oracle, cfg):
     """decimate -> UDPSinkFEC::write framing -> cm256_encode, ragged calls, frames straddling
     calls, meta stamped per call; expected = oracle decimator + framer + frame_encode."""
