@@ -150,9 +150,12 @@ int sdrhip_fec_encode_frames(sdrhip_ctx *ctx, const uint8_t *frames, size_t nfra
  * blocks, the first 128 datagrams of each frame in arrival order (originals and recovery
  * mixed; the reference relies on recovery blocks arriving last, :210); payload_out =
  * nframes x 127 x 508 bytes (blocks 1..127 in place, i.e. 16129 IQ samples per frame);
- * block0_out (may be NULL) = nframes x 508 bytes (the meta block).  rx is always host
- * memory for the headers' sake when mem == SDRHIP_MEM_HOST; with SDRHIP_MEM_DEVICE the
- * block indices are passed separately in `indices` (nframes x 128 bytes, host). */
+ * block0_out (may be NULL) = nframes x 508 bytes (the meta block).  The block indices are
+ * header.blockIndex of the super blocks (:147), read on the device; `indices` (may be NULL;
+ * nframes x 128 bytes, HOST memory in either mode) overrides them.  Planning (which
+ * originals are missing, the inverse of the Cauchy block, the recovery matrix of every
+ * frame) runs on the GPU: a batch may hold any number of distinct loss patterns and the
+ * device-memory form never synchronises with the host. */
 int sdrhip_fec_decode_frames(sdrhip_ctx *ctx, const uint8_t *rx, const uint8_t *indices, size_t nframes,
                              uint8_t *payload_out, uint8_t *block0_out, int mem);
 

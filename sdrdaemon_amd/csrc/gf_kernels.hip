@@ -331,6 +331,242 @@ __global__ void fec_header_kernel(const uint8_t *frames, size_t in_frame_bytes, 
     *reinterpret_cast<unsigned *>(rec + (size_t)f * out_frame_bytes + (size_t)r * 512) = (h0 & 0xffffu) | ((unsigned)(first_index + r) << 16);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Decode planning on the device (SDRdaemonFECBuffer::writeAndRead, .cpp:143-213, + CM256Decoder::Initialize /
+// Decode / DecodeM1 of the library behind cm256_decode): one workgroup per frame, no host involvement.
+//
+// From the 128 block indices of a frame in arrival order (the headers' blockIndex, or a caller-supplied array) it
+// derives: where every received original goes (pmap: payload block, zmap: the meta block 0), which originals were
+// erased (ascending, one per received recovery block, in array order: the pairing cm256 uses), and the
+// n_rec x 128 matrix that turns the received blocks into the erased ones,
+//     recovered_t = XOR_p coef[t][p] * block[p].
+// The system to solve is M[i][t] = (y_t ^ x_0) / (x_i ^ y_t) (x_i = index of the i-th received recovery block,
+// y_t = t-th erased original, x_0 = 128): a Cauchy matrix with scaled columns, whose inverse has the closed form
+//     Minv[t][i] = PX_i PY_t / ((x_i ^ y_t) QX_i QY_t (y_t ^ x_0)),
+//     PX_i = prod_k (x_i ^ y_k), PY_t = prod_k (x_k ^ y_t), QX_i = prod_{k != i} (x_i ^ x_k), QY_t = prod_{k != t} (y_t ^ y_k)
+// (characteristic 2: no signs), O(N) logarithm sums per row / column instead of a Gauss-Jordan elimination per
+// pattern on the host.  Columns of received originals: coef[t][p] = XOR_i Minv[t][i] * (y'_p ^ x_0) / (x_i ^ y'_p).
+// Mirrored quirks: exactly one received recovery block takes DecodeM1's XOR shortcut whatever its row; a repeated
+// original or recovery index is the library's "decode error" (-5): the frame keeps what was received (holes = 0).
+struct DecPlanArgs {
+    const uint8_t *rx;         // frames: [nframes][128][512], header byte 2 = block index
+    size_t rx_frame_bytes;
+    const uint8_t *indices;    // optional [nframes][128] (device); NULL = read the headers
+    const uint8_t *explog;     // exp[512] bytes, then log[256] as uint16 (device)
+    uint8_t *coef;             // [nframes][128][128]
+    int16_t *pmap, *zmap;      // [nframes][128] destination of position p (payload block / block 0) or -1
+    int16_t *pdst, *zdst;      // [nframes][128] destination of row t (payload block / block 0) or -1
+    int32_t *nrec;             // [nframes][2]: rows to apply, row that recovers block 0 exists (0 / 1)
+    uint8_t *payload_out;      // zero fill of the frames that stay incomplete
+    size_t payload_frame_bytes;
+    uint8_t *block0_out;       // may be NULL
+    int nframes;
+};
+
+__global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
+{
+    constexpr int K = 128;
+    __shared__ uint8_t s_exp[512];
+    __shared__ uint16_t s_log[256];
+    __shared__ uint8_t s_idx[K], s_x[K], s_y[K], s_rank[K];
+    __shared__ int s_cnt[K];
+    __shared__ int s_lpx[K], s_lqx[K], s_lpy[K], s_lqy[K];
+    __shared__ uint8_t s_linv[K * K]; // log of Minv[t][i] (a Cauchy inverse has no zero entry)
+    __shared__ uint8_t s_le[K * K];   // log of (y'_p ^ x_0) / (x_i ^ y'_p) at [i][p]
+    __shared__ int s_bad;
+    const int f = blockIdx.x, p = threadIdx.x;
+    for (int i = p; i < 512; i += K) s_exp[i] = a.explog[i];
+    for (int i = p; i < 256; i += K) s_log[i] = reinterpret_cast<const uint16_t *>(a.explog + 512)[i];
+    const int b = a.indices ? a.indices[(size_t)f * K + p] : a.rx[(size_t)f * a.rx_frame_bytes + (size_t)p * 512 + 2];
+    s_idx[p] = (uint8_t)b;
+    s_cnt[p] = 0;
+    if (p == 0) s_bad = 0;
+    __syncthreads();
+    if (b < K) atomicAdd(&s_cnt[b], 1);
+    __syncthreads();
+    // ranks: of this position among the recovery blocks (array order), of original index p among the missing ones
+    int rrank = 0, nrec = 0, mrank = 0, nmiss = 0, dup = 0;
+    for (int q = 0; q < K; ++q) {
+        const int r = s_idx[q] >= K;
+        nrec += r;
+        rrank += r && q < p;
+        const int m = s_cnt[q] == 0;
+        nmiss += m;
+        mrank += m && q < p;
+        dup |= s_cnt[q] > 1;
+    }
+    const bool is_rec = b >= K;
+    if (is_rec) { s_x[rrank] = (uint8_t)b; s_rank[p] = (uint8_t)rrank; }
+    if (s_cnt[p] == 0 && mrank < nrec) s_y[mrank] = (uint8_t)p; // erased originals, ascending (nmiss == nrec without repeats)
+    __syncthreads();
+
+    int16_t *pmap = a.pmap + (size_t)f * K, *zmap = a.zmap + (size_t)f * K, *pdst = a.pdst + (size_t)f * K, *zdst = a.zdst + (size_t)f * K;
+    pmap[p] = (b >= 1 && b < K) ? (int16_t)(b - 1) : (int16_t)-1;
+    zmap[p] = b == 0 ? (int16_t)0 : (int16_t)-1;
+
+    const int N = nrec;
+    bool ok = N > 0 && !dup;
+    if (ok && N >= 2) {
+        // logarithm sums of the four products
+        if (p < N) {
+            const int xi = s_x[p], yt = s_y[p];
+            int lpx = 0, lqx = 0, lpy = 0, lqy = 0, sing = 0;
+            for (int k = 0; k < N; ++k) {
+                lpx += s_log[xi ^ s_y[k]];
+                lpy += s_log[s_x[k] ^ yt];
+                if (k != p) {
+                    const int dx = xi ^ s_x[k];
+                    sing |= dx == 0; // the same recovery block twice: singular
+                    lqx += s_log[dx];
+                    lqy += s_log[yt ^ s_y[k]];
+                }
+            }
+            if (sing) atomicOr(&s_bad, 1);
+            s_lpx[p] = lpx % 255; s_lqx[p] = lqx % 255; s_lpy[p] = lpy % 255; s_lqy[p] = lqy % 255;
+        }
+        __syncthreads();
+        ok = !s_bad;
+        if (ok) {
+            for (int e = p; e < N * N; e += K) {
+                const int t = e / N, i = e - t * N;
+                const int yt = s_y[t], xi = s_x[i];
+                const int num = s_lpx[i] + s_lpy[t];
+                const int den = s_log[xi ^ yt] + s_lqx[i] + s_lqy[t] + s_log[yt ^ K];
+                s_linv[t * K + i] = (uint8_t)((num + 4 * 255 - den) % 255);
+            }
+            if (!is_rec)
+                for (int i = 0; i < N; ++i) s_le[i * K + p] = (uint8_t)((s_log[b ^ K] + 255 - s_log[s_x[i] ^ b]) % 255);
+        }
+        __syncthreads();
+    }
+
+    int32_t *meta = a.nrec + (size_t)f * 2;
+    if (!ok) {
+        // nothing to repair, or cm256's "decode error": the frame keeps what was received (SDRdaemonFECBuffer.cpp:199)
+        pdst[p] = -1; zdst[p] = -1;
+        if (p == 0) { meta[0] = 0; meta[1] = 0; }
+        if (nmiss > 0) { // some original never arrived: zero fill (initDecodeSlot, .cpp:109), the scatter pass comes after
+            unsigned *po = reinterpret_cast<unsigned *>(a.payload_out + (size_t)f * a.payload_frame_bytes);
+            for (int i = p; i < 127 * 127; i += K) po[i] = 0u;
+            if (a.block0_out && p < 127) reinterpret_cast<unsigned *>(a.block0_out + (size_t)f * 508)[p] = 0u;
+        }
+        return;
+    }
+    // destination of the recovered rows
+    {
+        int16_t pd = -1, zd = -1;
+        if (p < N) {
+            const int y = s_y[p];
+            if (y >= 1) pd = (int16_t)(y - 1);
+            else zd = 0;
+        }
+        pdst[p] = pd; zdst[p] = zd;
+        if (p == 0) { meta[0] = N; meta[1] = s_y[0] == 0; } // (ascending: block 0, when erased, is row 0)
+    }
+    uint8_t *coef = a.coef + (size_t)f * K * K;
+    if (N == 1) { // DecodeM1: XOR of everything that was received
+        coef[p] = 1;
+        return;
+    }
+    for (int t = 0; t < N; ++t) {
+        unsigned v;
+        if (is_rec) {
+            v = s_exp[s_linv[t * K + s_rank[p]]];
+        } else {
+            v = 0;
+            for (int i = 0; i < N; ++i) v ^= s_exp[(int)s_linv[t * K + i] + (int)s_le[i * K + p]];
+        }
+        coef[(size_t)t * K + p] = (uint8_t)v;
+    }
+}
+
+// out[f][dst[f][t]] = XOR_p coef[f][t][p] * in[f][p] with one matrix PER FRAME (the device planner's): the two
+// half-waves of a wave work on different frames and fetch different multiplier tables (two LDS addresses per read
+// instead of one broadcast); rows beyond a frame's count are skipped.  which = 0: payload rows, 1: the row that
+// recovers block 0.
+struct DecApplyArgs {
+    const uint8_t *in;
+    size_t in_frame_bytes;
+    uint8_t *out;
+    size_t out_frame_bytes;
+    int out_pitch;
+    const uint8_t *coef;       // [nframes][128][128]
+    const int16_t *dst;        // [nframes][128]
+    const int32_t *nrec;       // [nframes][2]
+    const uint8_t *tab;
+    int which;
+    int nframes;
+};
+
+template <int RB> __global__ __launch_bounds__(GF_NT) void gf_decode_apply_kernel(DecApplyArgs a)
+{
+    constexpr int K = 128, ROWS_PER_WG = 4 * RB;
+    __shared__ __attribute__((aligned(16))) unsigned tab[256 * 8];
+    __shared__ __attribute__((aligned(16))) uint8_t coef[2][ROWS_PER_WG * K];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, l = lane & 31;
+    const int row0 = blockIdx.y * ROWS_PER_WG;
+    const int f0 = blockIdx.x * 2;
+    int rows[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int fr = f0 + u;
+        int n = 0;
+        if (fr < a.nframes) n = a.which ? (a.nrec[(size_t)fr * 2 + 1] ? 1 : 0) : a.nrec[(size_t)fr * 2];
+        rows[u] = n;
+    }
+    if (row0 >= rows[0] && row0 >= rows[1]) return; // (uniform: nothing to recover here)
+    for (int i = tid; i < 256 * 8; i += GF_NT) tab[i] = reinterpret_cast<const unsigned *>(a.tab)[i];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint8_t *cg = a.coef + ((size_t)(f0 + u) * K + row0) * K;
+        const int nr = rows[u] - row0;
+        for (int i = tid; i < ROWS_PER_WG * K / 4; i += GF_NT) {
+            const int r = (i * 4) / K;
+            reinterpret_cast<unsigned *>(coef[u])[i] = (r < nr) ? reinterpret_cast<const unsigned *>(cg)[i] : 0u;
+        }
+    }
+    __syncthreads();
+    const int fr = f0 + h;
+    const int myrows = rows[h];
+    const int r0 = wave * RB;
+    if (row0 + r0 >= rows[0] && row0 + r0 >= rows[1]) return;
+
+    uint4_t acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = (uint4_t){0u, 0u, 0u, 0u};
+    const bool live = fr < a.nframes && row0 + r0 < myrows;
+    const uint8_t *fbase = a.in + (size_t)(fr < a.nframes ? fr : 0) * a.in_frame_bytes + 4;
+    const uint8_t *cw = coef[h] + r0 * K;
+    uint4_t xn = (uint4_t){0u, 0u, 0u, 0u};
+    if (live) xn = load_slab(fbase, l);
+    for (int j = 0; j < K; ++j) {
+        const uint4_t x = xn;
+        if (j + 1 < K && live) xn = load_slab(fbase + (size_t)(j + 1) * 512, l);
+        const Sel s0 = make_sel(x.x), s1 = make_sel(x.y), s2 = make_sel(x.z), s3 = make_sel(x.w);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const unsigned m = cw[rb * K + j];
+            const uint4_t t = *reinterpret_cast<const uint4_t *>(&tab[m * 8]);
+            const unsigned tc = tab[m * 8 + 4];
+            acc[rb].x ^= mulc(s0, t, tc);
+            acc[rb].y ^= mulc(s1, t, tc);
+            acc[rb].z ^= mulc(s2, t, tc);
+            acc[rb].w ^= mulc(s3, t, tc);
+        }
+    }
+    if (!live) return;
+    const int16_t *dst = a.dst + (size_t)fr * K;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int r = row0 + r0 + rb;
+        if (r >= myrows) break;
+        const int db = dst[r];
+        if (db < 0) continue;
+        store_slab(a.out + (size_t)fr * a.out_frame_bytes + (size_t)db * a.out_pitch, l, acc[rb]);
+    }
+}
+
 } // namespace
 
 hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream)
@@ -375,6 +611,48 @@ hipError_t launch_fec_headers(const uint8_t *frames, size_t in_frame_bytes, uint
     hipLaunchKernelGGL(fec_header_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, frames, in_frame_bytes, rec, out_frame_bytes,
                        nb_fec, first_index, nframes, frame_list, nlist);
     return hipGetLastError();
+}
+
+} // namespace sdrhip
+
+namespace sdrhip {
+
+hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices_dev,
+                                         const uint8_t *explog, const uint8_t *tab, int nframes, uint8_t *payload_out,
+                                         size_t payload_frame_bytes, uint8_t *block0_out, int max_rows, hipStream_t stream)
+{
+    if (nframes <= 0) return hipSuccess;
+    DecPlanArgs p;
+    p.rx = rx; p.rx_frame_bytes = rx_frame_bytes; p.indices = indices_dev; p.explog = explog;
+    p.coef = d.coef; p.pmap = d.pmap; p.zmap = d.zmap; p.pdst = d.pdst; p.zdst = d.zdst; p.nrec = d.nrec;
+    p.payload_out = payload_out; p.payload_frame_bytes = payload_frame_bytes; p.block0_out = block0_out; p.nframes = nframes;
+    hipLaunchKernelGGL(gf_decode_plan_kernel, dim3(nframes), dim3(128), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // received originals into place
+    e = launch_block_scatter(rx, rx_frame_bytes, 512, 4, payload_out, payload_frame_bytes, 508, 0, d.pmap, 128, nframes, stream);
+    if (e != hipSuccess) return e;
+    if (block0_out) {
+        e = launch_block_scatter(rx, rx_frame_bytes, 512, 4, block0_out, 508, 508, 0, d.zmap, 128, nframes, stream);
+        if (e != hipSuccess) return e;
+    }
+    // erased originals: rows 0 .. nrec[f] of every frame's matrix (workgroups beyond a frame's count leave at once)
+    DecApplyArgs a;
+    a.in = rx; a.in_frame_bytes = rx_frame_bytes; a.out = payload_out; a.out_frame_bytes = payload_frame_bytes; a.out_pitch = 508;
+    a.coef = d.coef; a.dst = d.pdst; a.nrec = d.nrec; a.tab = tab; a.which = 0; a.nframes = nframes;
+    if (max_rows < 1) max_rows = 1;
+    if (max_rows > 128) max_rows = 128;
+    const int groups = (nframes + 1) / 2;
+    if (max_rows <= 16) hipLaunchKernelGGL(gf_decode_apply_kernel<4>, dim3(groups, 1), dim3(GF_NT), 0, stream, a);
+    else hipLaunchKernelGGL(gf_decode_apply_kernel<6>, dim3(groups, (max_rows + 23) / 24), dim3(GF_NT), 0, stream, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (block0_out) {
+        a.out = block0_out; a.out_frame_bytes = 508; a.dst = d.zdst; a.which = 1;
+        hipLaunchKernelGGL(gf_decode_apply_kernel<4>, dim3(groups, 1), dim3(GF_NT), 0, stream, a);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 } // namespace sdrhip

@@ -124,6 +124,14 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
     cm256_karatsuba_leaf_tables(kl.data());
     if (hipMalloc(reinterpret_cast<void **>(&c->enc_leaves), kl.size()) != hipSuccess ||
         hipMemcpy(c->enc_leaves, kl.data(), kl.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "upload encoder constants"); }
+    {
+        const GF256 &g = gf();
+        uint8_t el[1024];
+        memcpy(el, g.exp, 512);
+        memcpy(el + 512, g.log, 512);
+        if (hipMalloc(reinterpret_cast<void **>(&c->gf_explog), sizeof(el)) != hipSuccess ||
+            hipMemcpy(c->gf_explog, el, sizeof(el), hipMemcpyHostToDevice) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "upload GF(256) exp/log tables"); }
+    }
     if (hipMalloc(reinterpret_cast<void **>(&c->decim_dump), 4096) != hipSuccess) { c->decim_dump = nullptr; ctx_free(c); return fail(SDRHIP_ENOMEM, "hipMalloc decimator scratch"); }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { ctx_free(c); return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
     *out = c;
@@ -157,8 +165,8 @@ static void sdrhip::ctx_free(sdrhip_ctx *c)
     if (c->enc_matrix) (void)hipFree(c->enc_matrix);
     if (c->enc_leaves) (void)hipFree(c->enc_leaves);
     if (c->decim_dump) (void)hipFree(c->decim_dump);
-    if (c->dec_coef) (void)hipFree(c->dec_coef);
-    if (c->dec_dst) (void)hipFree(c->dec_dst);
+    if (c->gf_explog) (void)hipFree(c->gf_explog);
+    c->dec_plan.release();
     c->pin.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -95,14 +95,8 @@ struct sdrhip_ctx {
     uint8_t *enc_leaves = nullptr;           // Karatsuba leaf tables of the structured k = 128 encoder (device)
     unsigned *decim_dump = nullptr;          // sink of the matrix-core decimator's warm-up stores (DecimArgs::mf_dump)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // decode-plan cache: erasure pattern (the 128 received block indices) -> matrix slot on the device
-    static constexpr int DEC_SLOTS = 64;
-    std::map<std::string, int> dec_slot_of;      // slot, or -1 for an undecodable pattern
-    std::vector<int> dec_nrec;                   // rows of each slot
-    std::vector<int> dec_free;                   // recycled slots
-    std::vector<char> dec_b0;                    // slot recovers block 0 (the meta block)
-    uint8_t *dec_coef = nullptr;                 // [DEC_SLOTS][128][128]
-    int16_t *dec_dst = nullptr;                  // [2][DEC_SLOTS][128]: payload destination, block-0 destination
+    uint8_t *gf_explog = nullptr;             // exp[512] + log[256] (uint16) of GF(256) for the decode planner (device)
+    sdrhip::DevBuf dec_plan;                  // per-frame decode plans of the current batch (DecodeBuffers)
     sdrhip::PinnedBuf pin;                       // per-call upload staging (maps, frame lists)
     // per-kernel-class timing with hipEvents on `stream` (sdrhip_ctx_kernel_timing)
     bool ktime_on = false;

@@ -146,4 +146,19 @@ hipError_t launch_block_scatter(const uint8_t *src, size_t src_frame_bytes, int 
 hipError_t launch_fec_headers(const uint8_t *frames, size_t in_frame_bytes, uint8_t *rec, size_t out_frame_bytes, int nb_fec,
                               int first_index, int nframes, const int32_t *frame_list, int nlist, hipStream_t stream);
 
+
+// device-side decode planning (gf_kernels.hip): work buffers of a batch of nframes
+struct DecodeBuffers {
+    uint8_t *coef;            // [nframes][128][128]
+    int16_t *pmap, *zmap;     // [nframes][128]
+    int16_t *pdst, *zdst;     // [nframes][128]
+    int32_t *nrec;            // [nframes][2]
+    static size_t bytes(size_t nframes) { return nframes * (128 * 128 + 4 * 128 * sizeof(int16_t) + 2 * sizeof(int32_t)) + 64; }
+};
+// plan + scatter + apply, all on the stream, no host synchronisation; max_rows = upper bound of the recovery blocks a
+// frame can have used (128 when unknown)
+hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices_dev,
+                                         const uint8_t *explog, const uint8_t *tab, int nframes, uint8_t *payload_out,
+                                         size_t payload_frame_bytes, uint8_t *block0_out, int max_rows, hipStream_t stream);
+
 } // namespace sdrhip

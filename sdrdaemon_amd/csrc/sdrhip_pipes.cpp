@@ -417,20 +417,11 @@ extern "C" int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t
     if (rx_stride_bytes < nframes * fb || out_stride < n_res) return fail(SDRHIP_EINVAL, "tx_process: stride too small");
     int rc;
     const uint8_t *drx = rx;
-    std::vector<uint8_t> idx;
     if (mem == SDRHIP_MEM_HOST) {
         if ((rc = tx->rxbuf.reserve((size_t)S * nframes * fb))) return rc;
         HIP_TRY(hipMemcpy2DAsync(tx->rxbuf.p, nframes * fb, rx, rx_stride_bytes, nframes * fb, S, hipMemcpyHostToDevice, c->stream));
         drx = tx->rxbuf.as<uint8_t>();
-        if (!indices) {
-            idx.resize((size_t)S * nframes * SDRHIP_NB_ORIGINAL);
-            for (int s = 0; s < S; ++s)
-                for (size_t i = 0; i < nframes * SDRHIP_NB_ORIGINAL; ++i)
-                    idx[(size_t)s * nframes * SDRHIP_NB_ORIGINAL + i] = rx[(size_t)s * rx_stride_bytes + i * SDRHIP_UDPSIZE + 2];
-            indices = idx.data();
-        }
     } else if (mem == SDRHIP_MEM_DEVICE) {
-        if (!indices) return fail(SDRHIP_EINVAL, "tx_process: device mode needs the host `indices` array");
         if (!aligned16(iq_out) || (S > 1 && (out_stride & 3))) return fail(SDRHIP_EALIGN, "tx_process: device output must be 16-byte aligned");
         if (S > 1 && rx_stride_bytes != nframes * fb) return fail(SDRHIP_EINVAL, "tx_process: device rx must be contiguous per stream");
     } else {
@@ -443,7 +434,7 @@ extern "C" int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t
         if ((rc = fec_decode_device(c, drx, fb, indices, (size_t)S * nframes, tx->payload.as<uint8_t>(), (size_t)127 * SDRHIP_BLOCK_BYTES, nullptr))) return rc;
     } else {
         for (int s = 0; s < S; ++s)
-            if ((rc = fec_decode_device(c, drx + (size_t)s * nframes * fb, fb, indices + (size_t)s * nframes * SDRHIP_NB_ORIGINAL, nframes,
+            if ((rc = fec_decode_device(c, drx + (size_t)s * nframes * fb, fb, indices ? indices + (size_t)s * nframes * SDRHIP_NB_ORIGINAL : nullptr, nframes,
                                         tx->payload.as<uint8_t>() + (size_t)s * pstride * 4, (size_t)127 * SDRHIP_BLOCK_BYTES, nullptr)))
                 return rc;
     }

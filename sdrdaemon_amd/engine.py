@@ -331,16 +331,15 @@ def fec_decode_frames(ctx, rx, indices=None, want_block0=False):
     F = rx.shape[0]
     if not is_t:
         rx = np.ascontiguousarray(rx, dtype=np.uint8)
-    if indices is None:
-        indices = (rx[:, :, 2].cpu().numpy() if is_t else rx[:, :, 2])
-    indices = np.ascontiguousarray(indices, dtype=np.uint8)
+    if indices is not None:  # optional: by default the library reads header.blockIndex of the super blocks itself
+        indices = np.ascontiguousarray(indices, dtype=np.uint8)
     if is_t:
         payload = torch.empty((F, 127 * 508), dtype=torch.uint8, device=rx.device)
         b0 = torch.empty((F, 508), dtype=torch.uint8, device=rx.device) if want_block0 else None
     else:
         payload = np.empty((F, 127 * 508), np.uint8)
         b0 = np.empty((F, 508), np.uint8) if want_block0 else None
-    check(ctx.lib.sdrhip_fec_decode_frames(ctx.h, _ptr(rx), C.c_void_p(indices.ctypes.data), F, _ptr(payload),
+    check(ctx.lib.sdrhip_fec_decode_frames(ctx.h, _ptr(rx), C.c_void_p(indices.ctypes.data if indices is not None else 0), F, _ptr(payload),
                                            _ptr(b0) if want_block0 else C.c_void_p(0), MEM_DEVICE if is_t else MEM_HOST))
     return (payload, b0) if want_block0 else payload
 
@@ -483,14 +482,13 @@ class TxPipe:
             rx = np.ascontiguousarray(rx, dtype=np.uint8)
         else:
             rx = rx.contiguous()
-        if indices is None:
-            indices = (rx[:, :, :, 2].cpu().numpy() if is_t else rx[:, :, :, 2])
-        indices = np.ascontiguousarray(indices, dtype=np.uint8)
+        if indices is not None:  # optional (see fec_decode_frames)
+            indices = np.ascontiguousarray(indices, dtype=np.uint8)
         n_res = (F * SAMPLES_PER_FRAME) << self.log2interp
         pad = (n_res + 3) & ~3
         out = (torch.empty((S, pad, 2), dtype=torch.int16, device=rx.device) if is_t else np.empty((S, pad, 2), np.int16))
         n_out = C.c_size_t(0)
-        check(self.ctx.lib.sdrhip_tx_process(self.h, _ptr(rx), C.c_void_p(indices.ctypes.data), F, F * NB_ORIGINAL * UDPSIZE,
+        check(self.ctx.lib.sdrhip_tx_process(self.h, _ptr(rx), C.c_void_p(indices.ctypes.data if indices is not None else 0), F, F * NB_ORIGINAL * UDPSIZE,
                                              _ptr(out), pad, C.byref(n_out), MEM_DEVICE if is_t else MEM_HOST))
         out = out[:, :n_res]
         return out[0] if squeeze else out

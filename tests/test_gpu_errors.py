@@ -34,8 +34,9 @@ def test_invalid_arguments_are_rejected_with_messages(ctx):
     assert "Invalid log2 interpolation factor" in str(e.value)
     with pytest.raises(sd.SdrHipError):
         sd.Decimators(ctx, 1, 5)
+    sd.RxPipe(ctx, 1, log2decim=0)  # (the filter-less settings are part of the pipe since K2 frames them)
     with pytest.raises(sd.SdrHipError):
-        sd.RxPipe(ctx, 1, log2decim=0)
+        sd.RxPipe(ctx, 1, log2decim=7)
     with pytest.raises(sd.SdrHipError):
         sd.RxPipe(ctx, 1, nb_fec=129)
 
