@@ -159,8 +159,8 @@ def test_decode_plan_cache_many_patterns(ctx, oracle):
 
 
 def test_decode_batch_with_more_patterns_than_cache_slots(ctx, oracle):
-    """150 frames, every one with its own erasure pattern, in ONE call: the batch goes through the 64-slot
-    plan cache in chunks."""
+    """150 frames, every one with its own erasure pattern, in ONE call (round 1 pushed such a batch through a
+    64-slot plan cache in chunks; the device planner takes it as it comes)."""
     import sdrdaemon_amd as sd
 
     R, F = 32, 150
@@ -176,6 +176,38 @@ def test_decode_batch_with_more_patterns_than_cache_slots(ctx, oracle):
         rx[f] = allb[[i for i in range(160) if i not in lost][:128]]
     assert len({rx[f, :, 2].tobytes() for f in range(F)}) > 2 * 64
     payload, b0 = sd.fec_decode_frames(ctx, rx, want_block0=True)
+    for f in range(F):
+        assert np.array_equal(payload[f].view(np.int16).reshape(-1, 2), x[f * 16129:(f + 1) * 16129]), f
+        assert np.array_equal(b0[f], frames[f, 0, 4:]), f
+
+
+def test_device_resident_batch_plans_on_the_gpu(ctx, oracle):
+    """Frames resident on the device, no index array from the host: the planner reads header.blockIndex itself.
+    Every frame has its own loss pattern; up to 128 losses out of 256 blocks (every original may be gone:
+    a 128 x 128 Cauchy block to invert), arrival order shuffled among the originals."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    R, F = 128, 24
+    rs = np.random.RandomState(5)
+    x = signals.noise(F * 16129, 91)
+    frames = oracle.framer(nb_fec_blocks=127).write(x)
+    frames[:, :, 3] = 0
+    rx = np.zeros((F, 128, 512), np.uint8)
+    for f in range(F):
+        nlost = [128, 127, 100, 64, 33, 2, 0][f % 7] if f < 21 else int(rs.randint(2, 129))
+        lost = set(rs.choice(256, nlost, replace=False).tolist())
+        if sum(1 for i in lost if i < 128) == 1:
+            lost.discard(128)  # (cm256's RecoveryCount == 1 shortcut quirk, covered by its own test)
+        allb = np.concatenate([frames[f], oracle.frame_encode(frames[f], R)])
+        got = [i for i in range(256) if i not in lost][:128]
+        orig = [i for i in got if i < 128]
+        rs.shuffle(orig)  # originals in any order, recovery blocks last (SDRdaemonFECBuffer.cpp:210)
+        rx[f] = allb[orig + [i for i in got if i >= 128]]
+    payload, b0 = sd.fec_decode_frames(ctx, torch.from_numpy(rx).cuda(), want_block0=True)
+    ctx.synchronize()
+    payload, b0 = payload.cpu().numpy(), b0.cpu().numpy()
     for f in range(F):
         assert np.array_equal(payload[f].view(np.int16).reshape(-1, 2), x[f * 16129:(f + 1) * 16129]), f
         assert np.array_equal(b0[f], frames[f, 0, 4:]), f

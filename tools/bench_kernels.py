@@ -102,6 +102,52 @@ if "tx" in what:
     nout = Stx * F * 16129 * 16
     print("tx pipe (decode 24 erasures + interpolate16) %8.3f ms / step  %8.1f Gsamples/s out  %7.1f GB/s (4.254 B/out)" %
           (dt * 1e3, nout / dt / 1e9, nout / dt / 1e9 * 4.254))
+if "tx-random" in what:
+    # config 4 under real loss: EVERY frame has its own random 24-erasure pattern (any of the 160 blocks), frames
+    # resident on the device, block indices read from the headers by the planning kernel; no host work per frame
+    import time
+
+    import numpy as np
+
+    F, R, Stx = 128, 32, 8
+    frames = torch.randint(0, 256, (Stx * F, 128, 512), generator=g, device=dev, dtype=torch.uint8)
+    frames[:, :, 2] = torch.arange(128, device=dev, dtype=torch.uint8)
+    rec = sd.fec_encode_frames(ctx, frames, R)
+    allb = torch.cat([frames, rec], dim=1)
+    rs = np.random.RandomState(3)
+    keep = np.stack([np.sort(rs.permutation(160)[:136])[:128] for _ in range(Stx * F)])  # 24 of 160 lost, first 128 arrivals
+    rx = allb[torch.arange(Stx * F, device=dev)[:, None], torch.from_numpy(keep).to(dev)].contiguous().reshape(Stx, F, 128, 512)
+    print("distinct loss patterns: %d of %d frames" % (len({k.tobytes() for k in keep}), Stx * F))
+    tx = sd.TxPipe(ctx, Stx, 4)
+    for _ in range(20):
+        y = tx.process(rx)
+    ctx.synchronize()
+    ctx.kernel_timing(True)
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        y = tx.process(rx)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    dms, dn = ctx.kernel_timing_read(K_FEC_DECODE)
+    ims, inn = ctx.kernel_timing_read(K_INTERPOLATE)
+    ctx.kernel_timing(False)
+    nout = Stx * F * 16129 * 16
+    print("   of which decode (plan + scatter + apply) %.3f ms, interpolator kernel %.3f ms per step" % (dms / max(dn, 1), ims / max(inn, 1)))
+    print("tx pipe, a random 24-erasure pattern per frame (%d frames/step): %8.3f ms / step  %8.1f Gsamples/s out  %7.1f GB/s (4.254 B/out)" %
+          (Stx * F, dt * 1e3, nout / dt / 1e9, nout / dt / 1e9 * 4.254))
+    # the same frames, one shared pattern (round 1's best case)
+    keep1 = np.tile(keep[:1], (Stx * F, 1))
+    rx1 = allb[torch.arange(Stx * F, device=dev)[:, None], torch.from_numpy(keep1).to(dev)].contiguous().reshape(Stx, F, 128, 512)
+    for _ in range(20):
+        tx.process(rx1)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tx.process(rx1)
+    ctx.synchronize()
+    dt1 = (time.perf_counter() - t0) / reps
+    print("tx pipe, one pattern shared by all frames: %8.3f ms / step (ratio distinct / shared = %.2f)" % (dt1 * 1e3, dt / dt1))
 if "host" in what:
     import time
 
