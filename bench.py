@@ -12,6 +12,13 @@ samples = 1 GiB of int16 IQ per GPU and step, resident in HBM before the timed r
 A step = one sdrhip_rx_process() call over that batch (decimate -> frame -> encode); the
 streams are continuous across steps (filter state and partial frames carry over).
 
+--streams N fixes the TOTAL number of streams of the job (the same 64 streams at
+1 / 2 / 4 / 8 GPUs, stream s on rank s mod G): "scaling" is then "strong"; without it every rank
+owns 8 streams ("weak").  At N = 1 the line also carries `configs`: the other single-GPU
+configurations of BASELINE.json measured in the same run (configs[1] decimate16_cen alone,
+configs[2] as ONE stream of 2^27 samples, configs[3] the Tx pipe with a different random
+24-erasure pattern in every frame), each with its own roofline object.
+
 Before the W warm-up steps the same step is run untimed for --preroll-seconds (default 0.25 s):
 the GPU's clocks ramp over the first ~60 ms of load (measured: 0.69 ms/step right after start,
 0.59 ms/step from ~60 ms on, flat over 2000 steps), which a small W would otherwise put into
@@ -53,12 +60,17 @@ def make_input(device, n, seed, kind):
     return x.to(torch.int16)
 
 
+def decim_kernel_name():
+    """the kernel sdrhip_decimate / sdrhip_rx_process run for decimate16_cen at this size (sdrhip.cpp: SDRHIP_DECIM_PATH)"""
+    return "decim_kernel<4,2,true>" if os.environ.get("SDRHIP_DECIM_PATH", "auto") == "valu" else "decim_mfma_kernel<4,true>"
+
+
 def pmc_traffic(samples_per_launch):
     """HBM bytes per launch of the decimator kernel from the committed PMC passes (profiles/traffic.json,
     collected with tools/prof.sh on this very command); None when the launch geometry differs."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f)["decim_kernel<4,2,true>"]
+            t = json.load(f)[decim_kernel_name()]
         if int(t["samples_per_launch"]) != int(samples_per_launch):
             return None
         return float(t["fetch_size_kb"]) * 1024.0 * float(t["fetch_correction"]) + float(t["write_size_kb"]) * 1024.0
@@ -74,7 +86,7 @@ def pmc_valu_lane_ops(samples_per_launch):
     """integer VALU lane-ops per launch of the decimator kernel (SQ_INSTS_VALU x 64, committed PMC pass)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f)["decim_kernel<4,2,true>"]
+            t = json.load(f)[decim_kernel_name()]
         if int(t["samples_per_launch"]) != int(samples_per_launch):
             return None
         return float(t["valu_wave_insts"]) * 64.0
@@ -162,12 +174,90 @@ def cpu_all_cores(budget_s):
             "sample": "%d threads x reference decimate16_cen on 2^20-sample blocks for %.1f s (decimation leg only)" % (ncpu, dt)}
 
 
+def timed_steps(ctx, fn, classes, steps=40, preroll_s=0.15):
+    """-> (wall ms per step, {kernel class: avg launch ms}) of fn() after a clock run-in"""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < preroll_s:
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+    ctx.kernel_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    per = {}
+    for c in classes:
+        ms, cnt = ctx.kernel_timing_read(c)
+        per[c] = ms / max(cnt, 1)
+    ctx.kernel_timing(False)
+    return wall, per
+
+
+def roof(bytes_per_launch, launch_ms, kernel):
+    ach = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "kernel": kernel, "avg_launch_ms": round(launch_ms, 4), "traffic": None}
+
+
+def extra_configs(ctx, dev, x, kind):
+    """The other single-GPU configurations of BASELINE.json, same process, same input tensors (VERDICT r1 #4)."""
+    import sdrdaemon_amd as sd
+    from sdrdaemon_amd.engine import K_DECIMATE, K_FEC_DECODE, K_INTERPOLATE
+
+    out = []
+    S, n = x.shape[0], x.shape[1]
+    # configs[1]: decimate16_cen alone, FEC off
+    d = sd.Decimators(ctx, S, sd.HB_EO1)
+    y = torch.empty((S, n >> LOG2DECIM, 2), dtype=torch.int16, device=dev)
+    wall, per = timed_steps(ctx, lambda: d.decimate(LOG2DECIM, sd.FC_CEN, 16, x, out=y), [K_DECIMATE])
+    out.append({"config": "configs[1]: %d streams x 2^%d samples, decimate16_cen (EO1), FEC off" % (S, n.bit_length() - 1),
+                "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
+                "roofline": roof(BYTES_DECIM * S * n, per[K_DECIMATE], decim_kernel_name())})
+    del y
+    # configs[2] literally: ONE stream (2^27 samples per step) through the fused Rx pipe
+    n1 = 1 << 27
+    x1 = make_input(dev, n1, 4000, kind)[None]
+    rx1 = sd.RxPipe(ctx, 1, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC)
+    wall, per = timed_steps(ctx, lambda: rx1.process_view(x1, tv_sec=1, tv_usec=0), [K_DECIMATE])
+    out.append({"config": "configs[2] as one stream: 2^27 samples per step, decimate16_cen + framing + CM256 128+32",
+                "ms_per_step": round(wall, 4), "value": round(n1 / wall / 1e3, 1), "unit": "Msamples/s (input)",
+                "roofline": roof(BYTES_DECIM * n1, per[K_DECIMATE], decim_kernel_name())})
+    del x1, rx1
+    # configs[3]: Tx pipe, 128+32 frames with 24 of the 160 blocks lost, a DIFFERENT random pattern in every frame,
+    # frames resident on the device (block indices read from the headers by the planning kernel), interpolate by 16
+    F, Stx = 128, 8
+    g = torch.Generator(device=dev).manual_seed(77)
+    frames = torch.randint(0, 256, (Stx * F, 128, 512), generator=g, device=dev, dtype=torch.uint8)
+    frames[:, :, 2] = torch.arange(128, device=dev, dtype=torch.uint8)
+    allb = torch.cat([frames, sd.fec_encode_frames(ctx, frames, NB_FEC)], dim=1)
+    rs = np.random.RandomState(3)
+    keep = np.stack([np.sort(rs.permutation(160)[:136])[:128] for _ in range(Stx * F)])
+    rxf = allb[torch.arange(Stx * F, device=dev)[:, None], torch.from_numpy(keep).to(dev)].contiguous().reshape(Stx, F, 128, 512)
+    tx = sd.TxPipe(ctx, Stx, LOG2DECIM)
+    wall, per = timed_steps(ctx, lambda: tx.process(rxf), [K_FEC_DECODE, K_INTERPOLATE])
+    nout = Stx * F * 16129 << LOG2DECIM
+    out.append({"config": "configs[3]: %d streams x %d frames per step, UDPSourceFEC decode 128+32 with 24 erased blocks (a distinct random "
+                          "pattern per frame, %d distinct) + interpolate16_cen" % (Stx, F, len({k.tobytes() for k in keep})),
+                "ms_per_step": round(wall, 4), "value": round(nout / wall / 1e3, 1), "unit": "Msamples/s (output)",
+                "decode_ms_per_step": round(per[K_FEC_DECODE], 4),
+                "roofline": roof((4.0 + 4.0 / 16.0) * nout, per[K_INTERPOLATE], "interp_kernel<4>"),
+                "pipe_gbps_config4": round((4.0 + 128.0 * 512.0 / 258064.0) * nout / (wall * 1e-3) / 1e9, 1)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2-samples", type=int, default=25, help="samples per stream per step (default 2^25)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="total streams of the job, sharded s -> rank s mod G (strong scaling, e.g. 64 = BASELINE configs[4]); "
+                         "default 0 = 8 streams per GPU (weak scaling)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the extra single-GPU configurations of the `configs` key")
     ap.add_argument("--input", choices=["noise", "testsource"], default="noise")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--preroll-seconds", type=float, default=0.25,
@@ -203,11 +293,21 @@ def main():
 
     dev = torch.device("cuda", local)
     ctx = sd.Context(local)
-    S, n = STREAMS_PER_GPU, 1 << args.log2_samples
-    # streams are sharded one-per-stream across ranks: global stream id = rank * S + s
+    n = 1 << args.log2_samples
+    # streams are sharded one-per-stream across ranks, no data-path collective
     from sdrdaemon_amd import sharding
 
-    x = torch.stack([make_input(dev, n, 1000 + sid, args.input) for sid in sharding.stream_ids(rank, world, S)])
+    if args.streams:
+        assert args.streams >= world, "--streams must be >= the number of GPUs"
+        ids = sharding.stream_ids_strong(rank, world, args.streams)  # stream s on rank s mod G
+    else:
+        ids = sharding.stream_ids(rank, world, STREAMS_PER_GPU)      # rank * 8 + s
+    S = len(ids)
+    ids_by_rank = [ids]
+    if dist is not None:  # (reporting only, outside the timed region)
+        ids_by_rank = [None] * world
+        dist.all_gather_object(ids_by_rank, ids)
+    x = torch.stack([make_input(dev, n, 1000 + sid, args.input) for sid in ids])
     rx = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
                    center_frequency_khz=435000, sample_rate=625000)
 
@@ -254,18 +354,23 @@ def main():
             "metric": "IQ Msamples/s through decim+FEC-encode pipe; bit-exact vs CPU ref",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "preroll_steps": preroll,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.streams else "weak",
             "vs_baseline": None, "dtype": "int32",
-            "data": "synthetic: %s, %d streams/GPU (stream id = rank*%d + s), HBM-resident before the timed region" %
-                    ("uniform random full-scale int16 IQ" if args.input == "noise" else "TestSource-like CW A=0.1 + dither", S, S),
-            "config": {"workload": "configs[2] x %d streams/GPU: 10 Msps-shaped int16 IQ, decimate16_cen (EO1) + UDPSinkFEC framing + "
-                                   "CM256 128+32 encode" % S,
-                       "streams_per_gpu": S, "samples_per_stream_per_step": n, "log2decim": LOG2DECIM, "fcpos": "cen",
+            "data": "synthetic: %s, %s, HBM-resident before the timed region" %
+                    ("uniform random full-scale int16 IQ" if args.input == "noise" else "TestSource-like CW A=0.1 + dither",
+                     ("%d streams in total, stream s on rank s mod %d" % (args.streams, world)) if args.streams else
+                     ("%d streams/GPU (stream id = rank*%d + s)" % (S, S))),
+            "config": {"workload": "configs[2] x %s: 10 Msps-shaped int16 IQ, decimate16_cen (EO1) + UDPSinkFEC framing + "
+                                   "CM256 128+32 encode" % (("%d streams over %d GPU(s) (configs[4] when 64 over 8)" % (args.streams, world))
+                                                            if args.streams else "%d streams/GPU" % S),
+                       "streams_per_gpu": S, "streams_total": args.streams if args.streams else S * world,
+                       "samples_per_stream_per_step": n, "log2decim": LOG2DECIM, "fcpos": "cen",
                        "nb_fec": NB_FEC, "hb_variant": "EO1", "frames_per_stream_per_step": frames // max(args.steps, 1), "output": "zero-copy view of the frame area",
-                       "parallelism": "stream-sharded x%d, no data-path collective" % world},
+                       "parallelism": "stream-sharded x%d, no data-path collective" % world,
+                       "stream_ids_by_rank": ids_by_rank if world * S <= 64 else "rank r: %s" % ("r, r+G, ..." if args.streams else "8r .. 8r+7")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(per_launch_samples),
-                         "kernel": "decim_kernel<L=4,FC=cen,PACK16>", "launches": dec_n, "avg_launch_ms": round(avg_ms, 4),
+                         "kernel": decim_kernel_name(), "launches": dec_n, "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": BYTES_DECIM * per_launch_samples,
                          "pipe_gbps_config3": round(BYTES_CONFIG3 * value * 1e6 / 1e9 / world, 1),
                          "fec_encode_avg_launch_ms": round(fec_ms / max(fec_n, 1), 4), "fec_encode_launches": fec_n},
@@ -276,6 +381,8 @@ def main():
             tl = lane_ops / (avg_ms * 1e-3) / 1e12
             res["roofline"]["valu"] = {"achieved": round(tl, 2), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "T lane-ops/s",
                                        "frac": round(tl / VALU_PEAK_TLANEOPS, 4), "lane_ops_per_sample": round(lane_ops / per_launch_samples, 2)}
+        if world == 1 and not args.no_configs:
+            res["configs"] = extra_configs(ctx, dev, x, args.input)
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             res["gpu_over_cpu_1core"] = round(value / res["cpu_baseline"]["value"], 1)

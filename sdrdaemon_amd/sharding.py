@@ -10,6 +10,13 @@ def stream_ids(rank, world_size, streams_per_gpu):
     return list(range(rank * streams_per_gpu, (rank + 1) * streams_per_gpu))
 
 
+def stream_ids_strong(rank, world_size, total_streams):
+    """Strong scaling: a fixed set of streams, stream s on rank s mod G."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    return list(range(rank, total_streams, world_size))
+
+
 def owner(stream_id, streams_per_gpu):
     return stream_id // streams_per_gpu
 

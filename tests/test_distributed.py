@@ -60,3 +60,31 @@ def test_single_process_passthrough():
     assert sharding.stream_ids(3, 8, 8) == list(range(24, 32))
     with pytest.raises(ValueError):
         sharding.stream_ids(8, 8, 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,scaling,total", [([], "weak", 16), (["--streams", "6"], "strong", 6)])
+def test_bench_two_ranks_execute_on_one_gpu(extra, scaling, total):
+    """The N > 1 branch of bench.py end to end (device selection, process group, barriers, sharded streams,
+    aggregate()) under torch.distributed.run: two ranks share GPU 0 and use gloo for the two reporting reductions
+    (--backend gloo; the driver's 8-GPU run uses nccl = RCCL).  That is all one GPU can show of the N > 1 path."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+           "--warmup", "1", "--cpu-seconds", "0", "--preroll-seconds", "0.05", "--log2-samples", "22"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == scaling and res["steps"] == 3
+    ids = res["config"]["stream_ids_by_rank"]
+    assert len(ids) == 2 and sorted(ids[0] + ids[1]) == list(range(total))  # disjoint cover of the job's streams
+    assert not set(ids[0]) & set(ids[1])
+    n = 1 << 22
+    # value = all ranks' samples / the slowest rank's time
+    assert res["value"] == pytest.approx(total * n * 3 / (res["ms_per_step"] * 3e-3) / 1e6, rel=1e-3)
+    assert res["value"] > 1000.0
