@@ -1,10 +1,7 @@
 // ref_fecbuf_shim.cpp -- C entry points around the REAL reference class SDRdaemonFECBuffer
-// (include/SDRdaemonFECBuffer.h, sdmnbase/SDRdaemonFECBuffer.cpp), compiled where it lies.
-// TEST INFRASTRUCTURE ONLY.  Built twice by oracle/Makefile:
-//   _ref/libsdrref_fecbuf_orc.so  with oracle/ref_cm256_orc/cm256.h (CM256 = the oracle, CPU):
-//                                 pins the oracle's restatement of the buffer logic;
-//   _ref/libsdrref_fecbuf_hip.so  with sdrdaemon_amd/adapters/cm256.h (CM256 = libsdrhip, GPU):
-//                                 the reference's own decoder call site running on the product.
+// (include/SDRdaemonFECBuffer.h, sdmnbase/SDRdaemonFECBuffer.cpp), compiled where it lies by tests/cxx/Makefile
+// against the product's cm256.h adapter (CM256 = libsdrhip.so on the GPU): the reference's own decoder call site
+// running on the product.  An integration test of the drop-in boundary, not an oracle.
 #include <cstddef>
 #include <cstdint>
 

@@ -84,6 +84,46 @@ def main():
     with open(os.path.join(HERE, "dsp_golden.json"), "w") as f:
         json.dump({"cases": index, "big": big}, f, indent=0)
     print("cases:", len(index), "arrays:", len(arrays))
+    fec_golden()
+
+
+def fec_golden():
+    """FEC vectors from the REAL cm256cc library (oracle/_ref/libsdrref_cm256.so, built by `make -C oracle
+    LIBCM256CCSRC=<dir>` where the library's sources exist).  Absent on this image: nothing is written and the FEC
+    half of the oracle stays unpinned (tests/test_oracle_vs_ref_cm256.py skips, tests/test_oracle_golden.py has no
+    FEC cases).  With it: recovery blocks for R = 1, 8, 32, 128 and decoded frames for the SURVEY 8d loss sets."""
+    import ctypes as C
+
+    from oracle_lib import ORACLE_DIR
+
+    lib = os.path.join(ORACLE_DIR, "_ref", "libsdrref_cm256.so")
+    if not os.path.exists(lib):
+        print("fec golden: cm256cc not available (oracle/_ref/libsdrref_cm256.so missing) - FEC parity stays unpinned")
+        return
+    L = C.CDLL(lib)
+    L.sdrref_cm256_encode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.sdrref_cm256_decode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    orig = np.ascontiguousarray(signals.noise(128 * 127, 900).view(np.uint8).reshape(128, 508))
+    arrays, index = {"fec_orig": orig}, []
+    for R in (1, 8, 32, 128):
+        rec = np.zeros((R, 508), np.uint8)
+        assert L.sdrref_cm256_encode(128, R, 508, orig.ctypes.data, rec.ctypes.data) == 0
+        arrays["fec_rec_R%d" % R] = rec
+        index.append({"kind": "cm256_encode", "k": 128, "R": R, "key": "fec_rec_R%d" % R})
+    allb = np.concatenate([orig, arrays["fec_rec_R32"]])
+    rs = np.random.RandomState(11)
+    for name, lost in (("fixed24", set(range(1, 121, 5))), ("random24", set(rs.choice(160, 24, replace=False).tolist()) | {0}),
+                       ("m1_row128", {7}), ("m1_row129", {7, 128})):
+        got = [i for i in range(160) if i not in lost][:128]
+        n_rec = sum(1 for i in got if i >= 128)
+        data, idx = np.ascontiguousarray(allb[got]), np.array(got, np.uint8)
+        rc = L.sdrref_cm256_decode(128, n_rec, 508, data.ctypes.data, idx.ctypes.data)
+        arrays["fec_dec_%s_data" % name], arrays["fec_dec_%s_idx" % name] = data, idx
+        index.append({"kind": "cm256_decode", "name": name, "received": got, "rc": int(rc), "key": "fec_dec_%s" % name})
+    np.savez_compressed(os.path.join(HERE, "fec_golden.npz"), **arrays)
+    with open(os.path.join(HERE, "fec_golden.json"), "w") as f:
+        json.dump({"cases": index}, f, indent=0)
+    print("fec golden cases:", len(index))
 
 
 if __name__ == "__main__":

@@ -1,9 +1,9 @@
-"""The reference's OWN SDRdaemonFECBuffer.cpp (compiled where it lies by oracle/Makefile) as a
-checker:
-  * CPU: over a CM256 backed by the oracle -> pins the oracle's restatement of the buffer logic
-    (block collection, first-128 policy, decode call, fix-up loop, frame change emission, stats);
-  * GPU: over sdrdaemon_amd/adapters/cm256.h = libsdrhip.so -> the reference's decoder call site
-    (SDRdaemonFECBuffer.cpp:148-213) runs unchanged on the product and matches the oracle."""
+"""The reference's OWN SDRdaemonFECBuffer.cpp, compiled where it lies (tests/cxx/Makefile) against the product's
+drop-in cm256.h adapter = libsdrhip.so: the reference's decoder call site (SDRdaemonFECBuffer.cpp:148-213: block
+collection, first-128 policy, decode call, fix-up loop, frame change emission, stats) runs unchanged on the GPU and
+gives what the oracle's restatement of the same chain gives.  (Round 1 also built that class over the ORACLE's CM256
+through a stand-in cm256.h; that build is gone: no reference code is compiled against headers of our own making
+except the adapter that IS the product's boundary.)"""
 import ctypes as C
 import os
 
@@ -11,11 +11,10 @@ import numpy as np
 import pytest
 
 import signals
-from oracle_lib import ORACLE_DIR
 
 
 def _load(name):
-    path = os.path.join(ORACLE_DIR, "_ref", name)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cxx", "_build", name)
     if not os.path.exists(path):
         pytest.skip("%s not built" % name)
     L = C.CDLL(path)
@@ -77,23 +76,6 @@ def _run_oracle(oracle, dgrams):
             outs.append(o.copy())
             stats.append((b.s.cur_nb_blocks, b.s.cur_nb_recovery))
     return outs, stats, (b.s.min_nb_blocks, b.s.max_nb_recovery)
-
-
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_oracle_fecbuffer_equals_reference_class(oracle, seed):
-    L = _load("libsdrref_fecbuf_orc.so")
-    x, dg = _datagrams(oracle, seed)
-    ro, rstats, rmm = _run_ref(L, dg)
-    oo, ostats, omm = _run_oracle(oracle, dg)
-    assert len(ro) == len(oo) == 6
-    for i in range(1, 6):  # emission 0 is the reference's uninitialised slot
-        assert np.array_equal(ro[i], oo[i]), i
-    assert rstats[1:] == ostats[1:]
-    # (min/max stats are not compared: the reference folds its uninitialised first slot into them,
-    # SDRdaemonFECBuffer.cpp:28-52 never clears m_decoderSlot)
-    # complete frames really carry the stream
-    for f in (0, 1, 2, 3):
-        assert np.array_equal(oo[f + 1].view(np.int16).reshape(-1, 2), x[f * 16129:(f + 1) * 16129]), f
 
 
 @pytest.mark.gpu
