@@ -159,6 +159,26 @@ int sdrhip_fec_encode_frames(sdrhip_ctx *ctx, const uint8_t *frames, size_t nfra
 int sdrhip_fec_decode_frames(sdrhip_ctx *ctx, const uint8_t *rx, const uint8_t *indices, size_t nframes,
                              uint8_t *payload_out, uint8_t *block0_out, int mem);
 
+/* ----------------------------------------------------------- TestSource bank -- */
+/* A bank of `nstreams` TestSource devices (include/TestSource.h:29-116, sdmnbase/TestSource.cpp) producing their
+ * 16-bit IQ samples straight into device memory: the input side of BASELINE configs 2-5 without an H2D copy.
+ * Configuration = the reference's key=value string (TestSource.cpp:59-215: srate, freq, dfp, dfn, power, blklen,
+ * fcpos, decim; same range checks, same error strings through sdrhip_last_error(), same quirks -- see
+ * sdrhip_testsource.cpp).  The sample arithmetic is NOT the reference's float phasor (not reproducible:
+ * -ffast-math, wrap bug :411-415) but an integer-exact NCO defined in testsource_kernels.hip and restated in
+ * oracle/sdr_oracle.c.  No real-time pacing (the reference sleeps one block time per block, :418). */
+typedef struct sdrhip_testsource sdrhip_testsource;
+int sdrhip_testsource_create(sdrhip_ctx *ctx, int nstreams, sdrhip_testsource **out);
+void sdrhip_testsource_destroy(sdrhip_testsource *ts);
+/* TestSource::configure(parsekv::pairs_type&): kv = "key=value,key=value" (',' or '&' separated, parsekv.h:40-43);
+ * stream = -1 configures every stream. */
+int sdrhip_testsource_configure(sdrhip_testsource *ts, int stream, const char *kv);
+/* get_sample_rate() / get_frequency() (TestSource.cpp:261-270), block length, forwarded decim / fcpos; any pointer may be NULL */
+int sdrhip_testsource_get(const sdrhip_testsource *ts, int stream, uint32_t *sample_rate, uint32_t *frequency, int *block_length,
+                          int *log2decim, int *fcpos);
+/* the next n samples of every stream (stream s at iq_out + 2*s*out_stride), phase continuous across calls */
+int sdrhip_testsource_read(sdrhip_testsource *ts, int16_t *iq_out, size_t n, size_t out_stride, int mem);
+
 /* ------------------------------------------------------------ fused Rx pipe -- */
 /* Bank of Rx chains: Downsampler::process (Downsampler.cpp:74-162) -> UDPSinkFEC::write
  * framing (UDPSinkFEC.cpp:79-191) -> encode section of transmitUDP (:228-256), i.e. what

@@ -629,3 +629,65 @@ int orc_fecbuffer_write_and_read(orc_fecbuffer *b, const uint8_t *sb, uint8_t *d
     }
     return available;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * TestSource bank.  The reference's generator (TestSource.cpp:395-422: float phasor, -ffast-math, a
+ * wrap bug at :411-415) is not reproducible, so the product defines an integer-exact NCO of its own; this is the
+ * independent statement of that definition the product is checked against:
+ *   phase(n) = phase0 + n * inc mod 2^32;  I = trunc(A * C[phase >> 20] / 2^30), Q = the same a quarter turn back;
+ *   C[i] = 2^30 cos(2 pi i / 4096) from a 31-step CORDIC in integers; inc = round(2^32 df / srate);
+ *   A(dB) in Q15 from dB steps of 10^(-1/20) in Q30.  Written table-free (the CORDIC runs per sample). */
+static const int orc_nco_atan[31] = {536870912, 316933406, 167458907, 85004756, 42667331, 21354465, 10679838, 5340245, 2670163, 1335087,
+                                     667544, 333772, 166886, 83443, 41722, 20861, 10430, 5215, 2608, 1304, 652, 326, 163, 81, 41, 20, 10, 5,
+                                     3, 1, 1};
+
+int orc_nco_cos_q30(unsigned idx12)
+{
+    int64_t z = (int64_t)(idx12 & 4095u) << 20;
+    int neg = 0;
+    if (z >= 0x80000000LL) z -= 0x100000000LL;
+    if (z > 0x40000000LL) { z -= 0x80000000LL; neg = 1; }
+    else if (z < -0x40000000LL) { z += 0x80000000LL; neg = 1; }
+    int64_t x = 652032874, y = 0;
+    for (int k = 0; k < 31; ++k) {
+        const int64_t xs = x >> k, ys = y >> k;
+        if (z >= 0) { x -= ys; y += xs; z -= orc_nco_atan[k]; }
+        else { x += ys; y -= xs; z += orc_nco_atan[k]; }
+    }
+    return (int)(neg ? -x : x);
+}
+
+unsigned orc_nco_phase_inc(int64_t df, int64_t srate)
+{
+    const int64_t num = df * 4294967296LL;
+    const int64_t q = num >= 0 ? (num + srate / 2) / srate : -((-num + srate / 2) / srate);
+    return (unsigned)(uint64_t)q;
+}
+
+int orc_nco_amp_q15(int db)
+{
+    int64_t a = 1LL << 30;
+    for (int i = 0; i < db && a > 0; ++i) a = (a * 956973408LL + (1LL << 29)) >> 30;
+    return (int)((a + (1LL << 14)) >> 15);
+}
+
+static int16_t orc_nco_scale(int amp, int c)
+{
+    const int64_t v = (int64_t)amp * c;
+    int64_t r = v >= 0 ? v >> 30 : -((-v) >> 30);
+    if (r > 32767) r = 32767;
+    if (r < -32768) r = -32768;
+    return (int16_t)r;
+}
+
+/* n IQ samples from phase0; returns the phase of the sample after the last one */
+unsigned orc_testsource_generate(unsigned phase0, unsigned inc, int amp_q15, size_t n, int16_t *iq_out)
+{
+    unsigned ph = phase0;
+    for (size_t k = 0; k < n; ++k, ph += inc) {
+        const unsigned idx = ph >> 20;
+        iq_out[2 * k] = orc_nco_scale(amp_q15, orc_nco_cos_q30(idx));
+        iq_out[2 * k + 1] = orc_nco_scale(amp_q15, orc_nco_cos_q30((idx - 1024u) & 4095u));
+    }
+    return ph;
+}

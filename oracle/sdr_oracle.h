@@ -164,4 +164,10 @@ int orc_fecbuffer_write_and_read(orc_fecbuffer *b, const uint8_t *superblock, ui
 #ifdef __cplusplus
 }
 #endif
+/* TestSource bank: the integer NCO the product defines (see sdr_oracle.c) */
+int orc_nco_cos_q30(unsigned idx12);
+unsigned orc_nco_phase_inc(int64_t df, int64_t srate);
+int orc_nco_amp_q15(int db);
+unsigned orc_testsource_generate(unsigned phase0, unsigned inc, int amp_q15, size_t n, int16_t *iq_out);
+
 #endif

@@ -29,6 +29,7 @@ EXPORTS = [
     "sdrhip_interpolators_reset", "sdrhip_interpolate", "sdrhip_cm256_encode", "sdrhip_cm256_decode",
     "sdrhip_fec_encode_frames", "sdrhip_fec_decode_frames", "sdrhip_rx_create", "sdrhip_rx_destroy", "sdrhip_rx_reconfigure", "sdrhip_rx_process",
     "sdrhip_rx_max_frames", "sdrhip_rx_frames_view", "sdrhip_tx_create", "sdrhip_tx_destroy", "sdrhip_tx_process",
+    "sdrhip_testsource_create", "sdrhip_testsource_destroy", "sdrhip_testsource_configure", "sdrhip_testsource_get", "sdrhip_testsource_read",
 ]
 
 
@@ -93,6 +94,12 @@ def load():
     lib.sdrhip_tx_destroy.argtypes = [vp]
     lib.sdrhip_tx_destroy.restype = None
     lib.sdrhip_tx_process.argtypes = [vp, vp, vp, sz, sz, vp, sz, C.POINTER(sz), i]
+    lib.sdrhip_testsource_create.argtypes = [vp, i, C.POINTER(vp)]
+    lib.sdrhip_testsource_destroy.argtypes = [vp]
+    lib.sdrhip_testsource_destroy.restype = None
+    lib.sdrhip_testsource_configure.argtypes = [vp, i, C.c_char_p]
+    lib.sdrhip_testsource_get.argtypes = [vp, i, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    lib.sdrhip_testsource_read.argtypes = [vp, vp, sz, sz, i]
     return lib
 
 

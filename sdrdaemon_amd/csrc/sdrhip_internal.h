@@ -69,6 +69,15 @@ hipError_t launch_decimate_simple(int log2decim, int fcpos, const int16_t *in, s
                                   size_t out_stride, size_t n_in, int nstreams, int norm, int trunk,
                                   hipStream_t stream);
 
+// TestSource bank (testsource_kernels.hip): one record per stream and call
+struct TestSourceParams {
+    unsigned phase0; // NCO phase of the call's first sample (2^32 = one turn)
+    unsigned inc;    // phase increment per sample
+    int amp;         // peak amplitude, Q15
+};
+hipError_t launch_testsource(const int *table, const TestSourceParams *par, int16_t *out, size_t out_stride, size_t n, int nstreams,
+                             hipStream_t stream);
+
 // K2 (frame_kernels.hip): stream-order samples -> super blocks of the frame area
 struct FrameArgs {
     const unsigned *in;   // [nstreams][in_stride] IQ dwords

@@ -211,6 +211,64 @@ class Downsampler:
         return self.m_decimators.decimate(0, self.m_fcPos, sample_size, samples_inout)
 
 
+class TestSource:
+    """Bank of the reference's TestSource devices (TestSource.h:29-116) generating on the GPU: configure() takes the
+    reference's control string / key-value map (TestSource.cpp:59-215), read() returns the next samples of every
+    stream as a CUDA tensor (or numpy with host=True).  The sample arithmetic is the library's integer NCO."""
+
+    def __init__(self, ctx, nstreams=1):
+        self.ctx, self.nstreams = ctx, nstreams
+        self.h = C.c_void_p()
+        self.m_error = ""
+        check(ctx.lib.sdrhip_testsource_create(ctx.h, nstreams, C.byref(self.h)))
+
+    def configure(self, m, stream=-1):
+        """-> bool like TestSource::configure; the message is kept for error()"""
+        kv = m if isinstance(m, str) else ",".join("%s=%s" % (k, v) for k, v in m.items())
+        try:
+            check(self.ctx.lib.sdrhip_testsource_configure(self.h, stream, kv.encode()))
+        except SdrHipError as e:
+            self.m_error = str(e)
+            return False
+        return True
+
+    def error(self):
+        e, self.m_error = self.m_error, ""
+        return e
+
+    def get(self, stream=0):
+        sr, fr, bl, dc, fc = C.c_uint32(0), C.c_uint32(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(self.ctx.lib.sdrhip_testsource_get(self.h, stream, C.byref(sr), C.byref(fr), C.byref(bl), C.byref(dc), C.byref(fc)))
+        return {"sample_rate": sr.value, "frequency": fr.value, "block_length": bl.value, "decim": dc.value, "fcpos": fc.value}
+
+    def get_sample_rate(self, stream=0):
+        return self.get(stream)["sample_rate"]
+
+    def get_frequency(self, stream=0):
+        return self.get(stream)["frequency"]
+
+    def read(self, n, host=False, out=None):
+        """-> (S, n, 2) int16 (squeezed for one stream)"""
+        S = self.nstreams
+        pad = (n + 3) & ~3
+        if out is None:
+            out = np.empty((S, pad, 2), np.int16) if host else torch.empty((S, pad, 2), dtype=torch.int16, device=torch.device("cuda", self.ctx.device))
+        check(self.ctx.lib.sdrhip_testsource_read(self.h, _ptr(out), n, out.shape[1], MEM_HOST if host else MEM_DEVICE))
+        y = out[:, :n]
+        return y[0] if S == 1 else y
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.sdrhip_testsource_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Interpolators:
     """Bank of reference `Interpolators` objects (Interpolators.h:35-61)."""
 

@@ -73,6 +73,12 @@ class Oracle:
         L.orc_framer_write.argtypes = [C.c_void_p, C.POINTER(C.c_int16), C.c_size_t, C.c_void_p]
         L.orc_frame_encode.restype = C.c_int
         L.orc_frame_encode.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_nco_cos_q30.argtypes = [C.c_uint]
+        L.orc_nco_phase_inc.argtypes = [C.c_int64, C.c_int64]
+        L.orc_nco_phase_inc.restype = C.c_uint
+        L.orc_nco_amp_q15.argtypes = [C.c_int]
+        L.orc_testsource_generate.argtypes = [C.c_uint, C.c_uint, C.c_int, C.c_size_t, C.c_void_p]
+        L.orc_testsource_generate.restype = C.c_uint
         L.orc_fecbuffer_init.argtypes = [C.c_void_p]
         L.orc_fecbuffer_write_and_read.restype = C.c_int
         L.orc_fecbuffer_write_and_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]
@@ -122,6 +128,12 @@ class Oracle:
             blocks[i].Index = int(indices[i])
         rc = self.lib.orc_cm256_decode(CM256Params(original_count, recovery_count, bb), blocks)
         return rc, np.array([blocks[i].Index for i in range(k)], dtype=np.uint8)
+
+    def testsource_generate(self, phase0, inc, amp_q15, n):
+        """-> ((n, 2) int16, phase after the last sample): the integer NCO the product's TestSource bank defines"""
+        out = np.zeros((n, 2), np.int16)
+        ph = self.lib.orc_testsource_generate(phase0, inc, amp_q15, n, out.ctypes.data)
+        return out, ph
 
     def framer(self, **kw):
         return OracleFramer(self, **kw)
