@@ -3,7 +3,7 @@
 // The reference's TestSource::read_samples (TestSource.cpp:395-422) is a float phasor, `amplitude * cos(phasor) * 32768`
 // truncated to int16, built with -ffast-math and with a wrap bug (:411-415): not bit-reproducible, so there is nothing
 // to be exact against.  This generator keeps the reference's configuration semantics (sdrhip_testsource.cpp) and
-// replaces the arithmetic by an integer-exact NCO of our own definition, restated in oracle/sdr_oracle.c:
+// replaces the arithmetic by an integer-exact NCO of our own definition, restated independently in the test oracle:
 //   phase(n) = phase0 + n * inc  (mod 2^32),  inc = round(2^32 * carrier offset / sample rate)
 //   I = trunc(A * C[phase >> 20] / 2^30),  Q = trunc(A * C[(phase >> 20) - 1024 mod 4096] / 2^30),  clamped to int16
 // with C[i] = 2^30 cos(2 pi i / 4096) from a 31-step integer CORDIC (host, sdrhip_testsource.cpp) and A the peak
