@@ -47,17 +47,24 @@ BYTES_DECIM = 4.0 + 4.0 / 16.0                      # kernel K1: read int16 IQ, 
 BYTES_CONFIG3 = 4.0 + 160.0 * 512.0 / 258064.0      # whole pipe incl. the 160 x 512 B frames
 
 
-def make_input(device, n, seed, kind):
-    g = torch.Generator(device=device).manual_seed(seed)
-    if kind == "noise":  # uniform full-scale int16 (the stress input of BASELINE.md 3.4, worst case for toggling)
-        return torch.randint(-32768, 32768, (n, 2), generator=g, device=device, dtype=torch.int16)
-    # TestSource-like CW (TestSource.cpp:395-422 shape, double precision) + 6 LSB of dither
-    k = torch.arange(n, device=device, dtype=torch.float64)
-    ph = 2.0 * np.pi * k * ((100e3 + 1e3 * seed) / 10e6)
-    a = 3276.8
-    x = torch.stack([torch.round(a * torch.cos(ph)), torch.round(a * torch.sin(ph))], dim=1)
-    x += torch.randint(-3, 4, (n, 2), generator=g, device=device).to(torch.float64)
-    return x.to(torch.int16)
+def make_input(ctx, device, n, seeds, kind):
+    """-> (len(seeds), n, 2) int16 on the device.  noise: uniform full-scale int16 (the stress input of BASELINE.md 3.4,
+    worst case for toggling); testsource: the library's TestSource bank (10 Msps, -20 dB CW at +100 kHz + 1 kHz per
+    stream id: TestSource.cpp:59-215 semantics, README.md:362 signal), generated on the device."""
+    if kind == "noise":
+        out = []
+        for seed in seeds:
+            g = torch.Generator(device=device).manual_seed(seed)
+            out.append(torch.randint(-32768, 32768, (n, 2), generator=g, device=device, dtype=torch.int16))
+        return torch.stack(out)
+    import sdrdaemon_amd as sd
+
+    ts = sd.TestSource(ctx, len(seeds))
+    for s, seed in enumerate(seeds):
+        assert ts.configure("srate=10000000,dfp=%d,power=20" % (100000 + 1000 * (seed % 1000)), s), ts.error()
+    x = ts.read(n)
+    ctx.synchronize()
+    return x.reshape(len(seeds), n, 2).contiguous()
 
 
 def decim_kernel_name():
@@ -219,7 +226,7 @@ def extra_configs(ctx, dev, x, kind):
     del y
     # configs[2] literally: ONE stream (2^27 samples per step) through the fused Rx pipe
     n1 = 1 << 27
-    x1 = make_input(dev, n1, 4000, kind)[None]
+    x1 = make_input(ctx, dev, n1, [4000], kind)
     rx1 = sd.RxPipe(ctx, 1, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC)
     wall, per = timed_steps(ctx, lambda: rx1.process_view(x1, tv_sec=1, tv_usec=0), [K_DECIMATE])
     out.append({"config": "configs[2] as one stream: 2^27 samples per step, decimate16_cen + framing + CM256 128+32",
@@ -307,7 +314,7 @@ def main():
     if dist is not None:  # (reporting only, outside the timed region)
         ids_by_rank = [None] * world
         dist.all_gather_object(ids_by_rank, ids)
-    x = torch.stack([make_input(dev, n, 1000 + sid, args.input) for sid in ids])
+    x = make_input(ctx, dev, n, [1000 + sid for sid in ids], args.input)
     rx = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
                    center_frequency_khz=435000, sample_rate=625000)
 
@@ -357,7 +364,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.streams else "weak",
             "vs_baseline": None, "dtype": "int32",
             "data": "synthetic: %s, %s, HBM-resident before the timed region" %
-                    ("uniform random full-scale int16 IQ" if args.input == "noise" else "TestSource-like CW A=0.1 + dither",
+                    ("uniform random full-scale int16 IQ" if args.input == "noise" else "GPU TestSource bank: 10 Msps CW, -20 dB, +100 kHz + 1 kHz x stream id",
                      ("%d streams in total, stream s on rank s mod %d" % (args.streams, world)) if args.streams else
                      ("%d streams/GPU (stream id = rank*%d + s)" % (S, S))),
             "config": {"workload": "configs[2] x %s: 10 Msps-shaped int16 IQ, decimate16_cen (EO1) + UDPSinkFEC framing + "
