@@ -229,6 +229,9 @@ int sdrhip_rx_frames_view(const sdrhip_rx *rx, const uint8_t **base, size_t *str
 typedef struct sdrhip_tx sdrhip_tx;
 int sdrhip_tx_create(sdrhip_ctx *ctx, int nstreams, int log2interp, sdrhip_tx **out);
 void sdrhip_tx_destroy(sdrhip_tx *tx);
+/* Upsampler::configure's `interp` key (Upsampler.cpp:31-50) between two sdrhip_tx_process calls, the way
+ * sdrdaemontx applies a control message (sdrdaemontx.cpp:381); the interpolator histories carry over. */
+int sdrhip_tx_reconfigure(sdrhip_tx *tx, int log2interp);
 int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t *indices, size_t nframes,
                       size_t rx_stride_bytes, int16_t *iq_out, size_t out_stride, size_t *n_out, int mem);
 

@@ -28,7 +28,7 @@ EXPORTS = [
     "sdrhip_decimators_reset", "sdrhip_decimate", "sdrhip_interpolators_create", "sdrhip_interpolators_destroy",
     "sdrhip_interpolators_reset", "sdrhip_interpolate", "sdrhip_cm256_encode", "sdrhip_cm256_decode",
     "sdrhip_fec_encode_frames", "sdrhip_fec_decode_frames", "sdrhip_rx_create", "sdrhip_rx_destroy", "sdrhip_rx_reconfigure", "sdrhip_rx_process",
-    "sdrhip_rx_max_frames", "sdrhip_rx_frames_view", "sdrhip_tx_create", "sdrhip_tx_destroy", "sdrhip_tx_process",
+    "sdrhip_rx_max_frames", "sdrhip_rx_frames_view", "sdrhip_tx_create", "sdrhip_tx_destroy", "sdrhip_tx_reconfigure", "sdrhip_tx_process",
     "sdrhip_testsource_create", "sdrhip_testsource_destroy", "sdrhip_testsource_configure", "sdrhip_testsource_get", "sdrhip_testsource_read",
 ]
 
@@ -91,6 +91,7 @@ def load():
     lib.sdrhip_rx_max_frames.argtypes = [vp, sz]
     lib.sdrhip_rx_max_frames.restype = sz
     lib.sdrhip_tx_create.argtypes = [vp, i, i, C.POINTER(vp)]
+    lib.sdrhip_tx_reconfigure.argtypes = [vp, i]
     lib.sdrhip_tx_destroy.argtypes = [vp]
     lib.sdrhip_tx_destroy.restype = None
     lib.sdrhip_tx_process.argtypes = [vp, vp, vp, sz, sz, vp, sz, C.POINTER(sz), i]

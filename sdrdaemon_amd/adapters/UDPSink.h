@@ -86,6 +86,14 @@ public:
         return (int)r;
     }
 
+    // non-blocking receive: the datagram length, 0 when nothing is queued, -1 on error
+    int recv_nowait(void *p, size_t n)
+    {
+        ssize_t r = ::recvfrom(m_fd, p, n, MSG_DONTWAIT, 0, 0);
+        if (r < 0) return (errno == EAGAIN || errno == EWOULDBLOCK || errno == EINTR) ? 0 : -1;
+        return (int)r;
+    }
+
 private:
     UdpSocket(const UdpSocket &);
     UdpSocket &operator=(const UdpSocket &);

@@ -7,9 +7,10 @@
 //                (UDPSinkFEC.cpp:79-191); a finished frame goes to the transmit thread through a ring
 //                of 8 slots (UDPSINKFEC_NBTXBLOCKS); write() blocks while the ring is full (the
 //                reference spins with usleep(100) and warns "UDP transmit too slow").
-//   tx thread    CM256-encodes the frame's nbBlocksFEC recovery blocks on the GPU
-//                (sdrhip_fec_encode_frames = the encode section of transmitUDP, :228-256) and sends the
-//                128 + nbBlocksFEC datagrams with usleep(txDelay) after each one (:259-282).
+//   tx thread    CM256-encodes the recovery blocks on the GPU (sdrhip_fec_encode_frames = the encode section of
+//                transmitUDP, :228-256): ALL the frames that are waiting in the ring with the same nbBlocksFEC go
+//                through one call; then sends each frame's 128 + nbBlocksFEC datagrams with usleep(txDelay)
+//                after each one (:259-282).
 //
 // Header-only, C++11, link with -lsdrhip -lpthread.  Owns a private sdrhip context (its transmit thread
 // must not share the process-wide one with the Decimators adapter on the main thread).  Without a GPU
@@ -120,7 +121,7 @@ private:
     static const int samplesPerBlock = (UDPSINKFEC_UDPSIZE - 4) / 4; // 127
 
     struct Slot {
-        unsigned char blocks[256][UDPSINKFEC_UDPSIZE]; // 128 originals, then up to 128 recovery super blocks
+        unsigned char blocks[UDPSINKFEC_NBORIGINALBLOCKS][UDPSINKFEC_UDPSIZE]; // the 128 originals (recovery blocks: the tx thread's batch buffer)
         std::uint16_t frameIndex;
         int nbBlocksFEC;
         int txDelay;
@@ -181,29 +182,49 @@ private:
 
     void transmit()
     {
+        std::vector<unsigned char> orig, rec;
         for (;;) {
+            int queued;
             {
                 std::unique_lock<std::mutex> lk(m_mutex);
                 while (m_queued == 0 && m_running) m_cond.wait(lk);
                 if (!m_running) return;
+                queued = m_queued;
             }
-            Slot &slot = m_slots[m_send];
-            int nb = slot.nbBlocksFEC;
+            // the waiting frames with the same fecblk as the first one: one GPU call for all of them
+            int nb = m_slots[m_send].nbBlocksFEC;
             if (nb < 0 || nb > 128 || !m_ctx) nb = 0;
-            if (nb > 0 && sdrhip_fec_encode_frames(m_ctx, &slot.blocks[0][0], 1, nb, &slot.blocks[UDPSINKFEC_NBORIGINALBLOCKS][0], SDRHIP_MEM_HOST) != SDRHIP_OK) {
-                std::cerr << "UDPSinkFEC::transmitUDP: CM256 encode failed (" << sdrhip_last_error() << "). No transmission." << std::endl;
-                return; // (the reference's transmit thread ends here as well, UDPSinkFEC.cpp:246-250)
+            int batch = 1;
+            while (batch < queued && m_slots[(m_send + batch) % UDPSINKFEC_NBTXBLOCKS].nbBlocksFEC == m_slots[m_send].nbBlocksFEC) ++batch;
+            if (nb > 0) {
+                const size_t fb = (size_t)UDPSINKFEC_NBORIGINALBLOCKS * UDPSINKFEC_UDPSIZE, rb = (size_t)nb * UDPSINKFEC_UDPSIZE;
+                const unsigned char *frames = &m_slots[m_send].blocks[0][0];
+                if (batch > 1) { // the slots are not adjacent in memory: gather the originals
+                    orig.resize((size_t)batch * fb);
+                    for (int b = 0; b < batch; ++b) std::memcpy(&orig[(size_t)b * fb], &m_slots[(m_send + b) % UDPSINKFEC_NBTXBLOCKS].blocks[0][0], fb);
+                    frames = &orig[0];
+                }
+                rec.resize((size_t)batch * rb);
+                if (sdrhip_fec_encode_frames(m_ctx, frames, (size_t)batch, nb, &rec[0], SDRHIP_MEM_HOST) != SDRHIP_OK) {
+                    std::cerr << "UDPSinkFEC::transmitUDP: CM256 encode failed (" << sdrhip_last_error() << "). No transmission." << std::endl;
+                    return; // (the reference's transmit thread ends here as well, UDPSinkFEC.cpp:246-250)
+                }
             }
-            for (int i = 0; i < UDPSINKFEC_NBORIGINALBLOCKS + nb; ++i) {
-                m_socket.send(slot.blocks[i], UDPSINKFEC_UDPSIZE);
-                usleep((useconds_t)(slot.txDelay > 0 ? slot.txDelay : 0));
+            for (int b = 0; b < batch; ++b) {
+                Slot &slot = m_slots[m_send];
+                for (int i = 0; i < UDPSINKFEC_NBORIGINALBLOCKS + nb; ++i) {
+                    const unsigned char *blk = i < UDPSINKFEC_NBORIGINALBLOCKS ? slot.blocks[i]
+                                                                                : &rec[((size_t)b * nb + (size_t)(i - UDPSINKFEC_NBORIGINALBLOCKS)) * UDPSINKFEC_UDPSIZE];
+                    m_socket.send(blk, UDPSINKFEC_UDPSIZE);
+                    usleep((useconds_t)(slot.txDelay > 0 ? slot.txDelay : 0));
+                }
+                {
+                    std::lock_guard<std::mutex> lk(m_mutex);
+                    --m_queued;
+                    m_send = (m_send + 1) % UDPSINKFEC_NBTXBLOCKS;
+                }
+                m_cond.notify_all();
             }
-            {
-                std::lock_guard<std::mutex> lk(m_mutex);
-                --m_queued;
-                m_send = (m_send + 1) % UDPSINKFEC_NBTXBLOCKS;
-            }
-            m_cond.notify_all();
         }
     }
 

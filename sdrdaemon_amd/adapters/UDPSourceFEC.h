@@ -2,15 +2,18 @@
 // UDPSourceFEC.cpp:28-105) together with the frame collector it owns (SDRdaemonFECBuffer,
 // SDRdaemonFECBuffer.cpp:28-250): same class name, constructor and virtuals, same frames out.
 //
-//   read()   receives 512-byte super blocks until the collector releases a frame, i.e. until the first
-//            datagram of the NEXT frame arrives (one frame of latency, SDRdaemonFECBuffer.cpp:133-139),
-//            and returns the 127 x 127 = 16129 samples of blocks 1..127.
-//   collector keeps the FIRST 128 super blocks of a frame in arrival order, originals in place, recovery
-//            blocks aside; with the 128th block it CM256-decodes the missing originals on the GPU
-//            (sdrhip_cm256_decode: the library's in-place contract, SDRdaemonFECBuffer.cpp:197-213) and
-//            updates the stream meta data from block 0; later blocks of the frame are only counted.
+//   read()   returns the 127 x 127 = 16129 samples (blocks 1..127) of the next frame.  A frame is released when the
+//            first datagram of ANOTHER frame arrives (one frame of latency, SDRdaemonFECBuffer.cpp:133-139).
+//   collector keeps the FIRST 128 super blocks of a frame in arrival order (.cpp:143-166); later blocks are only
+//            counted.  Unlike the reference it does not decode frame by frame: read() drains whatever the socket
+//            already holds, and every released frame that used recovery blocks goes to the GPU in ONE
+//            sdrhip_fec_decode_frames call (plan + scatter + apply on the device, up to MAXBATCH frames); frames
+//            without recovery blocks, and incomplete ones (holes stay zero, "incomplete frame" is logged), are put
+//            together on the host.  Results wait in a queue; read() hands them out one per call, together with the
+//            statistics of that frame (getCurNbBlocks ... getMaxNbRecovery, status string) and the stream meta data.
 //   quirks kept: the very first read() returns the collector's initial (zeroed) slot; getSampleBytes() /
-//            getSampleBits() stay at the base class defaults (the reference never updates them).
+//            getSampleBits() stay at the base class defaults (the reference never updates them); exactly one
+//            recovery block = cm256's XOR shortcut whatever its row (inside the library).
 //
 // Header-only, C++11, link with -lsdrhip.  Owns a private sdrhip context.  Without a GPU it behaves like
 // the reference without a valid CM256: frames with missing originals come out with holes (zeros).
@@ -18,6 +21,7 @@
 #define SDRHIP_UDPSOURCEFEC_ADAPTER_H
 
 #include <cstdio>
+#include <deque>
 #include <iostream>
 #include <vector>
 
@@ -44,9 +48,8 @@ public:
 #pragma pack(pop)
 
     UDPSourceFEC(const std::string &address, unsigned int port)
-        : UDPSource(address, port, UDPSOURCEFEC_UDPSIZE), m_ctx(0), m_frame(NB * BLOCK), m_recovery(NB * BLOCK), m_desc(NB),
-          m_blockCount(0), m_recoveryCount(0), m_decoded(false), m_metaRetrieved(false), m_frameHead(-1), m_curNbBlocks(0),
-          m_curNbRecovery(0), m_minNbBlocks(256), m_maxNbRecovery(0)
+        : UDPSource(address, port, UDPSOURCEFEC_UDPSIZE), m_ctx(0), m_curNbBlocks(0), m_curNbRecovery(0), m_minNbBlocks(256),
+          m_maxNbRecovery(0)
     {
         const char *dev = std::getenv("SDRHIP_DEVICE");
         if (sdrhip_ctx_create(dev ? std::atoi(dev) : 0, 0, &m_ctx) != SDRHIP_OK) {
@@ -55,6 +58,7 @@ public:
         }
         initMeta(m_currentMeta);
         initMeta(m_outputMeta);
+        m_open.reset(-1); // m_frameHead = -1 (SDRdaemonFECBuffer.cpp:36): the first datagram releases this empty slot
         m_socket.bindLocal(m_address, m_port, m_error);
     }
 
@@ -67,18 +71,35 @@ public:
     virtual void read(IQSampleVector &samples_out)
     {
         unsigned char sb[UDPSOURCEFEC_UDPSIZE];
-        std::vector<unsigned char> data((NB - 1) * BLOCK);
-        size_t dataLength = 0;
-        bool dataAvailable = false;
-        while (!dataAvailable) {
-            const int received = m_socket.recv(sb, sizeof(sb), 1000);
-            if (received < 0) { m_error = "UDPSourceFEC::read: receive error"; return; } // (samples_out untouched)
-            if (received == UDPSOURCEFEC_UDPSIZE) dataAvailable = writeAndRead(sb, &data[0], dataLength);
+        while (m_ready.empty()) {
+            // wait for the datagram that releases a frame ...
+            while (m_closed.empty()) {
+                const int received = m_socket.recv(sb, sizeof(sb), 1000);
+                if (received < 0) { m_error = "UDPSourceFEC::read: receive error"; return; } // (samples_out untouched)
+                if (received == UDPSOURCEFEC_UDPSIZE) feed(sb);
+            }
+            // ... then take what the socket already holds: more released frames make a bigger batch for the GPU
+            while ((int)m_closed.size() < MAXBATCH) {
+                const int received = m_socket.recv_nowait(sb, sizeof(sb));
+                if (received <= 0) break;
+                if (received == UDPSOURCEFEC_UDPSIZE) feed(sb);
+            }
+            decodeClosed();
         }
-        if (dataLength > 0) {
-            samples_out.resize(dataLength / 4);
-            std::memcpy(&samples_out[0], &data[0], dataLength);
+        Ready &r = m_ready.front();
+        samples_out.resize((size_t)(NB - 1) * BLOCK / 4);
+        std::memcpy(&samples_out[0], &r.frame[BLOCK], (size_t)(NB - 1) * BLOCK); // blocks 1..127
+        // meta data and statistics of the frame handed out (SDRdaemonFECBuffer.cpp:72-110,170-247)
+        if (r.meta && r.decoded && std::memcmp(&r.frame[0], &m_currentMeta, 12) != 0) {
+            std::memcpy(&m_currentMeta, &r.frame[0], sizeof(MetaDataFEC));
+            printMeta(m_currentMeta);
         }
+        if (r.meta && std::memcmp(&r.frame[0], &m_outputMeta, 12) != 0) std::memcpy(&m_outputMeta, &r.frame[0], sizeof(MetaDataFEC));
+        m_curNbBlocks = r.count;
+        m_curNbRecovery = r.nrec;
+        if (m_curNbBlocks < m_minNbBlocks) m_minNbBlocks = m_curNbBlocks;
+        if (m_curNbRecovery > m_maxNbRecovery) m_maxNbRecovery = m_curNbRecovery;
+        m_ready.pop_front();
     }
 
     /** appends ":<status>:<min blocks>/<max recovery>" (UDPSourceFEC.cpp:80-95) */
@@ -101,70 +122,6 @@ public:
     int getMinNbBlocks() { const int v = m_minNbBlocks; m_minNbBlocks = 256; return v; }      // reading resets
     int getMaxNbRecovery() { const int v = m_maxNbRecovery; m_maxNbRecovery = 0; return v; }
 
-    // one super block in, at most one frame (127 x 508 bytes) out -- SDRdaemonFECBuffer::writeAndRead
-    bool writeAndRead(const unsigned char *sb, unsigned char *data, size_t &dataLength)
-    {
-        bool dataAvailable = false;
-        dataLength = 0;
-        const int frameIndex = sb[0] | (sb[1] << 8);
-        if (m_frameHead != frameIndex) { // first datagram of another frame: release the slot as it is
-            dataLength = (size_t)(NB - 1) * BLOCK;
-            std::memcpy(data, &m_frame[BLOCK], dataLength); // blocks 1..127
-            if (m_metaRetrieved && std::memcmp(&m_frame[0], &m_outputMeta, 12) != 0) std::memcpy(&m_outputMeta, &m_frame[0], sizeof(MetaDataFEC));
-            if (!m_decoded)
-                std::cerr << "SDRdaemonFECBuffer::getSlotData: incomplete frame: m_blockCount: " << m_blockCount
-                          << " m_recoveryCount: " << m_recoveryCount << std::endl;
-            dataAvailable = true;
-            // statistics of the released frame, then an empty slot
-            m_curNbBlocks = m_blockCount;
-            m_curNbRecovery = m_recoveryCount;
-            if (m_curNbBlocks < m_minNbBlocks) m_minNbBlocks = m_curNbBlocks;
-            if (m_curNbRecovery > m_maxNbRecovery) m_maxNbRecovery = m_curNbRecovery;
-            m_blockCount = 0;
-            m_recoveryCount = 0;
-            m_decoded = false;
-            m_metaRetrieved = false;
-            std::fill(m_frame.begin(), m_frame.end(), 0);
-            m_frameHead = frameIndex;
-        }
-        if (m_blockCount < NB) { // still collecting the first 128
-            const int blockIndex = sb[2];
-            sdrhip_cm256_block &d = m_desc[m_blockCount];
-            d.Index = (unsigned char)blockIndex;
-            if (blockIndex == 0) m_metaRetrieved = true;
-            if (blockIndex < NB) {
-                d.Block = &m_frame[(size_t)blockIndex * BLOCK];
-            } else {
-                d.Block = &m_recovery[(size_t)m_recoveryCount * BLOCK];
-                ++m_recoveryCount;
-            }
-            std::memcpy(d.Block, sb + 4, BLOCK);
-        }
-        ++m_blockCount;
-        if (m_blockCount == NB) { // 128 blocks in: decode
-            m_decoded = true;
-            if (m_ctx && m_recoveryCount > 0) {
-                sdrhip_cm256_params p = {NB, m_recoveryCount, BLOCK};
-                if (sdrhip_cm256_decode(m_ctx, p, &m_desc[0]) != SDRHIP_OK) {
-                    std::cerr << "SDRdaemonFECBuffer::writeAndRead: CM256 decode error" << std::endl;
-                } else {
-                    std::cerr << "SDRdaemonFECBuffer::writeAndRead: CM256 decode success: nb recovery blocks: " << m_recoveryCount << std::endl;
-                    // the reference takes the LAST m_recoveryCount descriptors for the recovered blocks (it counts
-                    // on the recovery blocks arriving after the originals, SDRdaemonFECBuffer.cpp:208-213)
-                    for (int ir = 0; ir < m_recoveryCount; ++ir) {
-                        const sdrhip_cm256_block &r = m_desc[NB - m_recoveryCount + ir];
-                        std::memmove(&m_frame[(size_t)r.Index * BLOCK], r.Block, BLOCK);
-                    }
-                }
-            }
-            if (m_metaRetrieved && std::memcmp(&m_frame[0], &m_currentMeta, 12) != 0) {
-                std::memcpy(&m_currentMeta, &m_frame[0], sizeof(MetaDataFEC));
-                printMeta(m_currentMeta);
-            }
-        }
-        return dataAvailable;
-    }
-
 private:
     static const int NB = UDPSOURCEFEC_NBORIGINALBLOCKS;
     static const int BLOCK = UDPSOURCEFEC_UDPSIZE - 4; // 508 protected bytes = 127 samples
@@ -182,13 +139,82 @@ private:
                   << std::endl;
     }
 
+    static const int MAXBATCH = 8; // frames per GPU call
+
+    // a frame being collected / released: the first 128 super blocks as they arrived, headers included
+    struct Collect {
+        int index;
+        int count, nrec; // all blocks seen; recovery blocks among the first 128
+        bool meta;       // block 0 is among them
+        std::vector<unsigned char> rx;
+        Collect() : index(-1), count(0), nrec(0), meta(false), rx((size_t)NB * UDPSOURCEFEC_UDPSIZE) {}
+        void reset(int idx) { index = idx; count = 0; nrec = 0; meta = false; }
+    };
+    // a frame ready to be handed out: 128 x 508 bytes (block 0 = meta), holes zero
+    struct Ready {
+        std::vector<unsigned char> frame;
+        int count, nrec;
+        bool meta, decoded;
+        Ready() : frame((size_t)NB * BLOCK, 0), count(0), nrec(0), meta(false), decoded(false) {}
+    };
+
+    // one super block into the collector (SDRdaemonFECBuffer.cpp:112-170 without the decode)
+    void feed(const unsigned char *sb)
+    {
+        const int frameIndex = sb[0] | (sb[1] << 8);
+        if (m_open.index != frameIndex) { // first datagram of another frame: release the slot as it is
+            m_closed.push_back(m_open);
+            m_open.reset(frameIndex);
+        }
+        if (m_open.count < NB) { // still collecting the first 128
+            std::memcpy(&m_open.rx[(size_t)m_open.count * UDPSOURCEFEC_UDPSIZE], sb, UDPSOURCEFEC_UDPSIZE);
+            if (sb[2] == 0) m_open.meta = true;
+            if (sb[2] >= NB) ++m_open.nrec;
+        }
+        ++m_open.count;
+    }
+
+    // the released frames -> m_ready, in order; those that used recovery blocks through ONE GPU call
+    void decodeClosed()
+    {
+        std::vector<size_t> gpu; // indices into m_ready of the frames that go to the GPU
+        std::vector<unsigned char> rxb;
+        for (std::deque<Collect>::iterator it = m_closed.begin(); it != m_closed.end(); ++it) {
+            m_ready.push_back(Ready());
+            Ready &r = m_ready.back();
+            r.count = it->count; r.nrec = it->nrec; r.meta = it->meta; r.decoded = it->count >= NB;
+            const int have = it->count < NB ? it->count : NB;
+            for (int p = 0; p < have; ++p) { // received originals in place
+                const unsigned char *sb = &it->rx[(size_t)p * UDPSOURCEFEC_UDPSIZE];
+                if (sb[2] < NB) std::memcpy(&r.frame[(size_t)sb[2] * BLOCK], sb + 4, BLOCK);
+            }
+            if (!r.decoded) {
+                if (it->index >= 0) // (the initial empty slot is released silently)
+                    std::cerr << "SDRdaemonFECBuffer::getSlotData: incomplete frame: m_blockCount: " << it->count
+                              << " m_recoveryCount: " << it->nrec << std::endl;
+            } else if (it->nrec > 0 && m_ctx) {
+                gpu.push_back(m_ready.size() - 1);
+                rxb.insert(rxb.end(), it->rx.begin(), it->rx.end());
+            }
+        }
+        m_closed.clear();
+        if (gpu.empty()) return;
+        std::vector<unsigned char> payload(gpu.size() * (size_t)(NB - 1) * BLOCK), b0(gpu.size() * (size_t)BLOCK);
+        if (sdrhip_fec_decode_frames(m_ctx, &rxb[0], 0, gpu.size(), &payload[0], &b0[0], SDRHIP_MEM_HOST) != SDRHIP_OK) {
+            std::cerr << "SDRdaemonFECBuffer::writeAndRead: CM256 decode error (" << sdrhip_last_error() << ")" << std::endl;
+            return; // the frames keep what was received
+        }
+        for (size_t g = 0; g < gpu.size(); ++g) {
+            Ready &r = m_ready[gpu[g]];
+            std::memcpy(&r.frame[0], &b0[g * BLOCK], BLOCK);
+            std::memcpy(&r.frame[BLOCK], &payload[g * (size_t)(NB - 1) * BLOCK], (size_t)(NB - 1) * BLOCK);
+        }
+    }
+
     sdrhip_ctx *m_ctx;
-    std::vector<unsigned char> m_frame;    // 128 x 508: originals in place (block 0 = meta)
-    std::vector<unsigned char> m_recovery; // up to 128 x 508: recovery blocks in arrival order
-    std::vector<sdrhip_cm256_block> m_desc; // descriptors of the first 128 blocks in arrival order
-    int m_blockCount, m_recoveryCount;
-    bool m_decoded, m_metaRetrieved;
-    int m_frameHead;
+    Collect m_open;
+    std::deque<Collect> m_closed;
+    std::deque<Ready> m_ready;
     int m_curNbBlocks, m_curNbRecovery, m_minNbBlocks, m_maxNbRecovery;
     MetaDataFEC m_currentMeta, m_outputMeta;
 };

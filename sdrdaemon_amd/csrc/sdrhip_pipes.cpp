@@ -391,6 +391,18 @@ extern "C" int sdrhip_tx_create(sdrhip_ctx *ctx, int nstreams, int log2interp, s
     return SDRHIP_OK;
 }
 
+// Upsampler::configure (Upsampler.cpp:31-50), applied between two batches like sdrdaemontx does with a control message
+// (sdrdaemontx.cpp:381): the six interpolator instances are shared by every interpolateN entry point
+// (Interpolators.h:47-52), so their histories carry over.
+extern "C" int sdrhip_tx_reconfigure(sdrhip_tx *tx, int log2interp)
+{
+    if (!tx) return fail(SDRHIP_EINVAL, "tx is NULL");
+    sdrhip::CtxLock lock_(tx->ctx);
+    if (log2interp < 0 || log2interp > 6) return fail(SDRHIP_EINVAL, "Invalid log2 interpolation factor"); // Upsampler.cpp:38-42
+    tx->log2interp = log2interp;
+    return SDRHIP_OK;
+}
+
 extern "C" void sdrhip_tx_destroy(sdrhip_tx *tx)
 {
     if (!tx) return;

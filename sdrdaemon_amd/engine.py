@@ -527,7 +527,24 @@ class TxPipe:
     def __init__(self, ctx, nstreams=1, log2interp=4):
         self.ctx, self.nstreams, self.log2interp = ctx, nstreams, log2interp
         self.h = C.c_void_p()
+        self.m_error = ""
         check(ctx.lib.sdrhip_tx_create(ctx.h, nstreams, log2interp, C.byref(self.h)))
+
+    def configure(self, m):
+        """The `interp` key of a control message (Upsampler::configure, Upsampler.cpp:31-50) between two batches;
+        -> bool, the message is kept for error()."""
+        if "interp" in m:
+            try:
+                check(self.ctx.lib.sdrhip_tx_reconfigure(self.h, int(m["interp"])))
+                self.log2interp = int(m["interp"])
+            except (ValueError, SdrHipError) as e:
+                self.m_error = str(e)
+                return False
+        return True
+
+    def error(self):
+        e, self.m_error = self.m_error, ""
+        return e
 
     def process(self, rx, indices=None):
         """rx (S, F, 128, 512) uint8 (or (F, 128, 512)) -> iq (S, F*16129 << log2interp, 2) int16"""

@@ -334,3 +334,22 @@ def test_one_very_long_stream_and_a_wide_bank(ctx, oracle):
         f = fr[s].cpu().numpy()
         for i in range(2):
             assert np.array_equal(f[i, :128], ee[i]) and np.array_equal(f[i, 128:], oracle.frame_encode(ee[i], 32)), (s, i)
+
+
+def test_tx_pipe_live_interp_change(ctx, oracle):
+    """`interp` control message between two batches (sdrhip_tx_reconfigure = Upsampler::configure): the shared
+    interpolator instances keep their histories, exactly like the reference's Interpolators members."""
+    import sdrdaemon_amd as sd
+
+    R = 8
+    x = signals.noise(3 * 16129, 71)
+    frames = oracle.framer(nb_fec_blocks=R).write(x)
+    tx = sd.TxPipe(ctx, 1, 4)
+    ou = oracle.interpolators()
+    assert not tx.configure({"interp": "7"}) and "Invalid log2 interpolation factor" in tx.error()
+    for f, log2 in ((0, 4), (1, 2), (2, 6)):
+        assert tx.configure({"interp": str(log2)})
+        allb = np.concatenate([frames[f], oracle.frame_encode(frames[f], R)])
+        rxb = allb[[i for i in range(136) if i not in (3, 77)][:128]]  # two originals lost
+        got = tx.process(rxb[None])
+        assert np.array_equal(got, ou.interpolate(log2, x[f * 16129:(f + 1) * 16129])), (f, log2)
