@@ -35,8 +35,8 @@ def sizes(rs, scale, k):
             out.append(int(scale * rs.randint(1, 9) + rs.randint(0, 4)))
         else:
             out.append(int(rs.randint(1, 40000) * (1 + 7 * (c == 5))))
-        if rs.rand() < 0.02:
-            out[-1] = int(rs.randint(300000, 2500000))  # many segments
+        if rs.rand() < 0.06:
+            out[-1] = int(rs.randint(300000, 2500000))  # many segments / many matrix-core waves
     return out
 
 
@@ -45,6 +45,10 @@ while time.time() - t0 < budget:
     it += 1
     rs = np.random.RandomState(seed0 * 100003 + it)
     what = rs.choice(["decim", "interp", "rx", "tx", "fec"], p=[0.3, 0.2, 0.2, 0.1, 0.2])
+    # decimator kernel selection per iteration: the VALU cascade, the matrix-core cascade (short spans so that small
+    # inputs run many waves + the VALU head / tail pieces), or the library's own choice
+    os.environ["SDRHIP_DECIM_PATH"] = str(rs.choice(["auto", "valu", "mfma", "mfma"]))
+    os.environ["SDRHIP_MFMA_SPAN"] = str(1024 * int(rs.choice([1, 1, 2, 3, 5, 16])))
     if what == "decim":
         S = int(rs.randint(1, 4))
         bias = int(rs.randint(0, 2))
@@ -94,22 +98,24 @@ while time.time() - t0 < budget:
                 assert np.array_equal(y[s], ous[s].interpolate(L, x[s])), ("interp", it, L, n, s)
     elif what == "rx":
         S = int(rs.randint(1, 3))
-        L = int(rs.randint(1, 5))
-        fc = 2 if L <= 2 else int(rs.randint(0, 3))
+        L = int(rs.randint(0, 5))
+        fc = int(rs.randint(0, 3))  # (decim 0 and inf / sup 1-2 are the filter-less settings framed by K2)
         R = int(rs.choice([0, 1, 7, 13, 32, 100]))
         bias = int(rs.randint(0, 2))
         rx = sd.RxPipe(ctx, S, log2decim=L, fcpos=fc, hb_variant=bias, nb_fec=R)
         ods = [orc.decimators(bias) for _ in range(S)]
         frs = [orc.framer(nb_fec_blocks=R) for _ in range(S)]
+        dev_rate = 625000 << L  # the pipe is created with the sink rate 625000: the device runs at 625000 * 2^decim
         for k in range(int(rs.randint(1, 6))):
             if k and rs.rand() < 0.3:  # control message between batches
-                L = int(rs.randint(1, 5))
-                fc = 2 if L <= 2 else int(rs.randint(0, 3))
+                L = int(rs.randint(0, 5))
+                fc = int(rs.randint(0, 3))
                 R = int(rs.choice([0, 1, 7, 13, 32, 100]))
                 assert rx.configure({"decim": L, "fcpos": fc, "fecblk": R}), rx.error()
                 for fr in frs:
                     fr.s.nb_fec_blocks = R
-            nd = int(rs.choice([3, 500, 16129, 16130, 8000, 40000, 70000]))
+                    fr.s.sample_rate = dev_rate >> L  # recomputed for every block (sdrdaemonrx.cpp:640-644)
+            nd = int(rs.choice([3, 500, 16129, 16130, 8000, 40000, 70000, 150000 >> max(L - 2, 0)]))
             x = np.stack([signals.noise(nd << L, int(rs.randint(1 << 30))) for _ in range(S)])
             if rs.rand() < 0.3:
                 import torch
@@ -181,7 +187,14 @@ while time.time() - t0 < budget:
                 keep = keep + [keep[0]] * (128 - len(keep))
             rxb[f] = allb[keep]
         tx = sd.TxPipe(ctx, 1, L)
-        y = np.asarray(tx.process(rxb)).reshape(-1, 2)
+        if rs.rand() < 0.4:  # frames resident on the device: the planning kernel reads the block indices from the headers
+            import torch
+
+            yt = tx.process(torch.from_numpy(rxb).cuda())
+            ctx.synchronize()
+            y = yt.cpu().numpy().reshape(-1, 2)
+        else:
+            y = np.asarray(tx.process(rxb)).reshape(-1, 2)
         assert np.array_equal(y, orc.interpolators().interpolate(L, x)), ("tx", it, F, R, L)
     stats[what] += 1
 print("fuzz OK: %d iterations in %.0f s: %s" % (it, time.time() - t0, stats))

@@ -20,7 +20,7 @@ def main():
                            "from kernels group by name order by sum(end-start) desc").fetchall()
         tot = sum(r[2] for r in rows) or 1
         print("%-90s %6s %12s %12s %12s %12s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
-        for r in rows[:5]:
+        for r in rows[:8]:
             print("%-90s %6d %12.1f %12.2f %12.2f %12.2f %6.1f" % (short(r[0]), r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3,
                                                                      100.0 * r[2] / tot))
         ccols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
@@ -32,7 +32,7 @@ def main():
             print("counters_collection columns:", ccols, e)
             continue
         for n in sorted(set(r[0] for r in pm)):
-            if "decim_kernel" in n or "decim_mfma" in n or "gf_" in n or "interp_kernel" in n or os.environ.get("ROCPD_ALL_KERNELS"):
+            if "decim_kernel" in n or "decim_mfma" in n or "frame_pack" in n or "gf_" in n or "interp_kernel" in n or os.environ.get("ROCPD_ALL_KERNELS"):
                 print("  PMC", short(n), "vgpr", [r[4] for r in pm if r[0] == n][0], "lds", [r[5] for r in pm if r[0] == n][0])
                 for r in pm:
                     if r[0] == n:
