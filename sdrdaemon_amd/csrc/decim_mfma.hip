@@ -11,16 +11,21 @@
 //    (FIR) or even (centre tap) input plane, one signed byte ("limb") of every entry.  Lane (column n, kq) of B
 //    holds entries 8 * (t >> 1) + 2 * kq + (t & 1) (byte t) of each block = exactly the values that lane
 //    (n, q = kq) of D produced two tiles of the previous stage ago: the FIR data path runs in registers, no
-//    cross-lane traffic except the centre-tap ring below and the final I / Q pairing.
+//    cross-lane traffic except the I / Q pairing of the raw loads and of the final outputs.
 //  * exactness: int16 input x = lo + 256 hi + 128 with signed bytes lo = (x & 255) ^ 128, hi = x >> 8 (the 128
 //    becomes a constant in the accumulator); stage outputs |v| <= 2^18 are split as v = b0 + 256 b1 + 65536 b2
-//    with signed bytes b = bytes of (v + 0x808080) ^ 0x808080; taps h = h0 + 256 h1.  The limb products of
+//    - 229248 with signed bytes b0, b1 = bytes 0, 1 of ((acc >>> 13) ^ 0x8080), b2 = bits 16-18 with bit 18 flipped (0..7):
+//    the 19-bit two's complement field with its sign bit flipped is v + 2^18, excess-128 bytes are signed bytes + 128,
+//    and the constant goes into the next stage's accumulator start; taps h = h0 + 256 h1.  The limb products of
 //    equal weight share an accumulator (|sum| < 2^21: no overflow), the four accumulators are recombined with
 //    shifts modulo 2^32 = the reference's wrap-around int32 sum.
-//  * the centre tap (x[2k - 30] << 13) needs no multiplier: the even outputs of a stage (even raw samples for the
-//    first stage) go as int32 through a 32-entry ring per column and stage in LDS (written by the lane that
-//    produced them, read four at a time by the lane that owns outputs k .. k+3) and enter the accumulator as
-//    (e << 13) + c.  The ring is private to the wave: no barrier, program order of the wave's DS operations.
+//  * the centre tap (x[2k - 30] << 13) rides in the same MFMAs: a 16-row tile needs 47 of the 64 entries of its
+//    window (three blocks), the fourth dword of the window -- the one the NEXT odd block will overwrite -- holds the
+//    16 even-plane entries k - 15 of the tile's rows, and the h1 limb matrix has the entry 32 (32 * 256 = 2^13)
+//    where row r meets even entry r - 15.  A lane's even entries come out of the same registers as its odd ones
+//    (outputs 4q, 4q+2 of the previous stage's tiles / even raw samples of its own load), one block later; the only
+//    irregularity is that the window of rows 16 I .. 16 I + 15 ends with even entry 16 I, the FIRST entry of the next
+//    block: lanes kq = 0 replace byte 0 (the unneeded entry 16 (I - 1)) with it.  No LDS, no cross-lane traffic.
 //  * the newest block of a window replaces the oldest in place (dword `phase` of the fragment), the tap
 //    matrices exist in the four rotations; the multi-rate schedule (stage s runs every 2^s steps) is unrolled
 //    over one period of 4 * 2^(NS-1) steps so that every phase is a compile-time constant.
@@ -59,7 +64,13 @@ constexpr MfATab mf_make_atab()
                     for (int t = 0; t < 4; ++t) {
                         const int d = r - mf_entry(kq, t) + 16 * beta; // delay of the entry w.r.t. output r, in plane entries
                         int v = 0;
-                        if (d >= 0 && d <= 31) {
+                        if (beta == 3) {
+                            // the dword the next odd block will replace: even-plane entries 16 (I - 1) + e, except that
+                            // slot (kq 0, t 0) carries entry 16 I; row r takes entry 16 I + r - 15 times 2^13 = 32 * 256
+                            const int e = mf_entry(kq, t);
+                            const bool hit = (kq == 0 && t == 0) ? r == 15 : e == r + 1;
+                            v = (m == 1 && hit) ? 32 : 0;
+                        } else if (d >= 0 && d <= 31) {
                             const int h = H32(d);
                             const int h1 = (h + 128) >> 8, h0 = h - 256 * h1;
                             v = m == 0 ? h0 : h1;
@@ -93,24 +104,21 @@ template <int N, class F> __device__ __forceinline__ void mf_static_for(F &&f)
 __device__ __forceinline__ int4_t mfma(int4_t a, int4_t b, int4_t c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
-// centre-tap ring (LDS, private to a wave): [stage][column][MF_RING_PITCH] int32; entry m of a stage's even
-// input plane sits at position m & 31
-constexpr int MF_RING_PITCH = 36;                      // dwords per column (32 + pad: 16-byte aligned, spreads the banks)
-constexpr int MF_RING_STAGE = 16 * MF_RING_PITCH;      // dwords per stage
-template <int NS> constexpr int mf_ring_dwords() { return 4 * NS * MF_RING_STAGE; } // per workgroup of four waves
-
 template <int NS> struct MfState {
-    int4_t O[NS][3];        // odd plane window of every stage, one signed byte per entry and limb
+    int4_t O[NS][3];        // window of every stage, one signed byte per entry and limb: three odd blocks + the even entries
     unsigned pend[NS][2];   // odd inputs of stage s >= 1: first half of the block being formed (limbs 0-1, limb 2)
+    unsigned evp[NS][2];    // even inputs, likewise
 };
+
+// value of a stage output in terms of its limbs: v = b0 + 256 b1 + 65536 b2 + MF_LIMB_BIAS
+constexpr int MF_LIMB_BIAS = 128 + 32768 - 262144;
 
 struct MfConst {
     int4_t A[2][4]; // tap matrices (limbs h0, h1) in the four rotations
-    int cin0;       // accumulator start of stage 0: 128 * (sum of the FIR taps) + (bias << 13)
-    int cinN;       // other stages: bias << 13
-    int *ring_wr;   // ring + column + 2 * q dwords: where this lane's even entries 2q, 2q+1 of a group of 8 go
-    int *ring_rd;   // ring + column + 4 * q dwords: entries 4q .. 4q+3 of a block
-    int *ring_rd4b; // entry 4q+4 of the odd-numbered block (wraps to entry 0 of the even one for q = 3)
+    int4_t c0;      // accumulator start of stage 0: 128 * (sum of the FIR taps + 2^13) + (bias << 13), in all four rows
+    int cinN;       // other stages: MF_LIMB_BIAS * (sum of the FIR taps + 2^13) + (bias << 13)
+    unsigned selA;  // v_perm selectors {new, old}: lanes kq = 0 take byte 0 (selA) / byte 2 (selB) of `new` into byte 0,
+    unsigned selB;  // the other lanes keep `old`
 };
 
 struct MfOut {
@@ -135,41 +143,22 @@ __device__ __forceinline__ unsigned opaque(unsigned v)
     return v;
 }
 
-// accumulator start of outputs 4q .. 4q+3 of tile I of stage S: c + (e << 13) with e = even-plane entry k - 15
-// (IntHalfbandFilterEO1.h:136-142); entries 16 (I-1) + 4q+1 .. 4q+4 of the ring
-template <int S, int I> __device__ __forceinline__ int4_t mf_centre(const MfConst &k, int c)
-{
-    constexpr int BP = (I + 3) & 1; // parity of block I - 1
-    // the entries were written by OTHER lanes of this wave: the compiler must not move the reads above ring stores
-    // it can prove disjoint per lane (the hardware executes a wave's DS operations in order)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int *rd = k.ring_rd + S * MF_RING_STAGE + 16 * BP;
-    const int4_t v = *reinterpret_cast<const int4_t *>(rd);
-    const int e4 = BP ? k.ring_rd4b[S * MF_RING_STAGE] : rd[4];
-    int4_t r;
-    r[0] = (int)lshl_add((unsigned)v[1], 13, (unsigned)c);
-    r[1] = (int)lshl_add((unsigned)v[2], 13, (unsigned)c);
-    r[2] = (int)lshl_add((unsigned)v[3], 13, (unsigned)c);
-    r[3] = (int)lshl_add((unsigned)e4, 13, (unsigned)c);
-    return r;
-}
-
 template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState<NS> &st, const MfConst &k, MfOut &oc, int comp)
 {
     constexpr int PH = I & 3;
     const int4_t Ah0 = k.A[0][PH], Ah1 = k.A[1][PH];
     const int4_t z = {0, 0, 0, 0};
-    int o[4];
+    unsigned acc[4];
     if constexpr (S == 0) {
-        int4_t g0 = mfma(Ah0, st.O[0][0], mf_centre<0, I>(k, k.cin0));
+        int4_t g0 = mfma(Ah0, st.O[0][0], k.c0);
         int4_t g1 = mfma(Ah0, st.O[0][1], z);
         int4_t g2 = mfma(Ah1, st.O[0][1], z);
         g1 = mfma(Ah1, st.O[0][0], g1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (int)lshl_add(opaque(lshl_add((unsigned)g2[r], 8, (unsigned)g1[r])), 8, (unsigned)g0[r]) >> 13;
+        for (int r = 0; r < 4; ++r) acc[r] = lshl_add(opaque(lshl_add((unsigned)g2[r], 8, (unsigned)g1[r])), 8, (unsigned)g0[r]);
     } else {
-        int4_t g0 = mfma(Ah0, st.O[S][0], mf_centre<S, I>(k, k.cinN));
+        const int4_t cN = {k.cinN, k.cinN, k.cinN, k.cinN};
+        int4_t g0 = mfma(Ah0, st.O[S][0], cN);
         int4_t g1 = mfma(Ah0, st.O[S][1], z);
         int4_t g2 = mfma(Ah0, st.O[S][2], z);
         int4_t g3 = mfma(Ah1, st.O[S][2], z);
@@ -177,24 +166,37 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
         g2 = mfma(Ah1, st.O[S][1], g2);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            o[r] = (int)lshl_add(opaque(lshl_add(opaque(lshl_add((unsigned)g3[r], 8, (unsigned)g2[r])), 8, (unsigned)g1[r])), 8, (unsigned)g0[r]) >> 13;
+            acc[r] = lshl_add(opaque(lshl_add(opaque(lshl_add((unsigned)g3[r], 8, (unsigned)g2[r])), 8, (unsigned)g1[r])), 8, (unsigned)g0[r]);
     }
 
     if constexpr (S < NS - 1) {
-        // outputs 4q .. 4q+3 of this tile: r = 0, 2 are even inputs of stage S+1 (entries 8 I + 2q, + 1 of its even
-        // plane: to the ring), r = 1, 3 odd ones (to the window, one signed byte per limb)
-        constexpr int SIG = I & 1, NJ = (I >> 1) & 3;
-        *reinterpret_cast<int2_t *>(k.ring_wr + (S + 1) * MF_RING_STAGE + 8 * (I & 3)) = (int2_t){o[0], o[2]};
-        const unsigned u1 = (unsigned)o[1] + 0x808080u, u3 = (unsigned)o[3] + 0x808080u;
+        // outputs 4q .. 4q+3 of this tile as 19-bit fields u = acc >>> 13 (limbs: bytes 0, 1 and bits 16-18).  r = 1, 3
+        // are odd inputs of stage S+1 (entries 8 I + 2q, + 1 of its odd plane), r = 0, 2 the same entries of its even plane
+        constexpr int SIG = I & 1, J = I >> 1;
+        const unsigned X = 0x80808080u, X2 = 0x04040404u;
+        const unsigned u0 = acc[0] >> 13, u1 = acc[1] >> 13, u2 = acc[2] >> 13, u3 = acc[3] >> 13;
         const unsigned po = perm(u3, u1, 0x05010400u), po2 = perm(u3, u1, 0x0c0c0602u);
+        const unsigned pe = perm(u2, u0, 0x05010400u), pe2 = perm(u2, u0, 0x0c0c0602u);
         if constexpr (SIG == 0) {
             st.pend[S + 1][0] = po; st.pend[S + 1][1] = po2;
+            // this tile's first even output (lanes q = 0) is entry 16 J of the even plane: the last one tile J of the
+            // next stage needs; the other 15 are in place since the previous block was completed (below)
+            constexpr int DJ = (J + 1) & 3;
+            st.O[S + 1][0][DJ] = (int)(perm(pe, (unsigned)st.O[S + 1][0][DJ], k.selA) ^ X);
+            st.O[S + 1][1][DJ] = (int)(perm(pe, (unsigned)st.O[S + 1][1][DJ], k.selB) ^ X);
+            st.O[S + 1][2][DJ] = (int)(perm(pe2, (unsigned)st.O[S + 1][2][DJ], k.selA) ^ X2);
+            st.evp[S + 1][0] = pe; st.evp[S + 1][1] = pe2;
         } else {
-            const unsigned X = 0x80808080u;
+            constexpr int NJ = J & 3, DN = (J + 2) & 3;
             st.O[S + 1][0][NJ] = (int)(perm(po, st.pend[S + 1][0], 0x05040100u) ^ X);
             st.O[S + 1][1][NJ] = (int)(perm(po, st.pend[S + 1][0], 0x07060302u) ^ X);
-            st.O[S + 1][2][NJ] = (int)(perm(po2, st.pend[S + 1][1], 0x05040100u) ^ X);
-            mf_stage<NS, S + 1, (I >> 1)>(st, k, oc, comp);
+            st.O[S + 1][2][NJ] = (int)(perm(po2, st.pend[S + 1][1], 0x05040100u) ^ X2);
+            // even block J (its limbs not yet made signed: that happens when the entry of lanes kq = 0 is merged in)
+            const unsigned e0 = perm(pe, st.evp[S + 1][0], 0x05040100u), e1 = perm(pe, st.evp[S + 1][0], 0x07060302u),
+                           e2 = perm(pe2, st.evp[S + 1][1], 0x05040100u);
+            mf_stage<NS, S + 1, J>(st, k, oc, comp);
+            // tile J was the last reader of odd block J - 2: its dword takes the even entries of tile J + 1
+            st.O[S + 1][0][DN] = (int)e0; st.O[S + 1][1][DN] = (int)e1; st.O[S + 1][2][DN] = (int)e2;
         }
     } else {
         // lanes n = 2p (I) and 2p + 1 (Q) hold the same outputs: both pack the same dwords and store them to the
@@ -203,8 +205,9 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
         unsigned pk[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int other = __builtin_amdgcn_update_dpp(0, o[r], 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
-            pk[r] = final_pack(comp ? other : o[r], comp ? o[r] : other, oc.norm, oc.trunk);
+            const int o = (int)acc[r] >> 13;
+            const int other = __builtin_amdgcn_update_dpp(0, o, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+            pk[r] = final_pack(comp ? other : o, comp ? o : other, oc.norm, oc.trunk);
         }
         unsigned *dst = oc.store ? oc.p : oc.dump;
         *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
@@ -212,7 +215,7 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
     }
 }
 
-template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, int *ring)
+template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw)
 {
     constexpr int L = NS;
     constexpr int P = 4 << (NS - 1);    // first-stage steps per period
@@ -228,7 +231,9 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
     const size_t S = a.mf_span;
     const size_t wave_start = a.mf_head + (size_t)ws * 8 * S; // first stored raw sample of column pair 0
     const char *wbase = reinterpret_cast<const char *>(a.in) + ((size_t)stream * a.in_stride + wave_start - W) * 4;
-    const unsigned loff = (unsigned)((size_t)p * S * 4) + 16u * (unsigned)q;
+    // the I lane of a column pair loads raw samples 4q .. 4q+3 of a step's 32, the Q lane 16 + 4q .. 16 + 4q+3; each
+    // extracts both components and hands the other one to its neighbour (one DPP move per plane)
+    const unsigned loff = (unsigned)((size_t)p * S * 4) + 16u * (unsigned)q + 64u * (unsigned)comp;
     const int T = (int)((W + S) / 32); // steps
     const int nper = T / P;
 
@@ -237,16 +242,15 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) k.A[m][ph] = *reinterpret_cast<const int4_t *>(&mf_atab.w[m][ph][lane][0]);
-    const int b13 = a.bias << 13;
-    k.cin0 = (int)opaque(128u * (unsigned)mf_tap_sum() + (unsigned)b13); // (opaque: hipcc otherwise splits it into (e + bias) << 13 + c, two ops)
-    k.cinN = b13;
+    const unsigned b13 = (unsigned)a.bias << 13;
+    const unsigned gain = (unsigned)mf_tap_sum() + 8192u; // FIR taps + centre tap
     {
-        int *col = ring + n * MF_RING_PITCH;
-        k.ring_wr = col + 2 * q;
-        k.ring_rd = col + 4 * q;
-        k.ring_rd4b = col + ((20 + 4 * q) & 31);
-        for (int i = lane; i < NS * MF_RING_STAGE; i += 64) ring[i] = 0;
+        const int c = (int)(128u * gain + b13); // x = lo + 256 hi + 128 on both planes
+        k.c0 = (int4_t){c, c, c, c};
     }
+    k.cinN = (int)((unsigned)MF_LIMB_BIAS * gain + b13);
+    k.selA = q == 0 ? 0x03020104u : 0x03020100u;
+    k.selB = q == 0 ? 0x03020106u : 0x03020100u;
 
     MfOut oc;
     oc.store = 0;
@@ -264,37 +268,42 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
 #pragma unroll
         for (int b = 0; b < 3; ++b) st.O[s][b] = (int4_t){0, 0, 0, 0};
         st.pend[s][0] = st.pend[s][1] = 0u;
+        st.evp[s][0] = st.evp[s][1] = 0u;
     }
 
-    const unsigned selc = comp ? 0x07030602u : 0x05010400u;
-    const int esh = comp ? 16 : 0;
-    uint4_t ld[D][2];
-    // step g of this lane's column: 128 bytes at src + 128 g.  No bounds handling: the loads run D steps past the end
-    // of the span, i.e. into the next span or (last span of a stream) the first 32 D samples of the tail that
+    // byte selectors: a sample dword is {I lo, I hi, Q lo, Q hi}
+    const unsigned sel_own = comp ? 0x07030602u : 0x05010400u; // {lo(a), lo(b), hi(a), hi(b)} of this lane's component
+    const unsigned sel_oth = comp ? 0x05010400u : 0x07030602u; // ... of the neighbour's
+    // {own half, received half} -> {first, second} half of the block: the I lane loaded the first half
+    const unsigned sel_lo = comp ? 0x05040100u : 0x01000504u, sel_hi = comp ? 0x07060302u : 0x03020706u;
+    unsigned ev_lo = 0u, ev_hi = 0u; // even entries of the previous step (limbs made signed)
+    uint4_t ld[D];
+    // step g of this lane's column pair: 128 bytes at src + 128 g.  No bounds handling: the loads run D steps past the
+    // end of the span, i.e. into the next span or (last span of a stream) the first 32 D samples of the tail that
     // plan_decimate_mfma() guarantees
     const char *src = wbase + loff;
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        ld[d][0] = *reinterpret_cast<const uint4_t *>(src + 128 * d);
-        ld[d][1] = *reinterpret_cast<const uint4_t *>(src + 128 * d + 64);
-    }
+    for (int d = 0; d < D; ++d) ld[d] = *reinterpret_cast<const uint4_t *>(src + 128 * d);
 
     for (int per = 0; per < nper; ++per) {
         oc.store = per > 0;
         mf_static_for<P>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int slot = i % D;
-            const uint4_t r0 = ld[slot][0], r1 = ld[slot][1];
-            ld[slot][0] = *reinterpret_cast<const uint4_t *>(src + 128 * (i + D));
-            ld[slot][1] = *reinterpret_cast<const uint4_t *>(src + 128 * (i + D) + 64);
-            // raw samples 4q .. 4q+3 (r0) and 16 + 4q .. (r1) of the step's 32: x, z even; y, w odd.
-            // even ones: entries 2q, 2q+1 and 8 + 2q, 8 + 2q+1 of block i of the first stage's even plane
-            int *wr = k.ring_wr + 16 * (i & 1);
-            *reinterpret_cast<int2_t *>(wr) = (int2_t){sbfe16(r0.x, esh), sbfe16(r0.z, esh)};
-            *reinterpret_cast<int2_t *>(wr + 8) = (int2_t){sbfe16(r1.x, esh), sbfe16(r1.z, esh)};
-            const unsigned ao = perm(r0.w, r0.y, selc), bo = perm(r1.w, r1.y, selc);
-            st.O[0][0][i & 3] = (int)(perm(bo, ao, 0x05040100u) ^ 0x80808080u);
-            st.O[0][1][i & 3] = (int)perm(bo, ao, 0x07060302u);
+            const uint4_t r = ld[slot];
+            ld[slot] = *reinterpret_cast<const uint4_t *>(src + 128 * (i + D));
+            // four samples x, y, z, w: y, w are odd-plane entries, x, z even-plane entries (2q, 2q + 1 of their half block)
+            const unsigned ao = perm(r.w, r.y, sel_own), ae = perm(r.z, r.x, sel_own);
+            const unsigned xo = perm(r.w, r.y, sel_oth), xe = perm(r.z, r.x, sel_oth);
+            const unsigned yo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xo, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+            const unsigned ye = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xe, 0xB1, 0xf, 0xf, true);
+            st.O[0][0][i & 3] = (int)(perm(ao, yo, sel_lo) ^ 0x80808080u);
+            st.O[0][1][i & 3] = (int)perm(ao, yo, sel_hi);
+            const unsigned cur_lo = perm(ae, ye, sel_lo) ^ 0x80808080u, cur_hi = perm(ae, ye, sel_hi);
+            // even entries of tile i: those of the previous step, and the first one of this step (lanes kq = 0)
+            st.O[0][0][(i + 1) & 3] = (int)perm(cur_lo, ev_lo, k.selA);
+            st.O[0][1][(i + 1) & 3] = (int)perm(cur_hi, ev_hi, k.selA);
+            ev_lo = cur_lo; ev_hi = cur_hi;
             mf_stage<NS, 0, i>(st, k, oc, comp);
         });
         src += 128 * P;
@@ -305,8 +314,7 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
 // workgroups (four waves = four groups of 8 spans each)
 template <int L, bool PACK16> __global__ __launch_bounds__(NT, MF_WAVES) void decim_mfma_kernel(DecimArgs a)
 {
-    constexpr int LDSDW = DecimLds<L, 2, PACK16>::dwords > mf_ring_dwords<L>() ? DecimLds<L, 2, PACK16>::dwords : mf_ring_dwords<L>();
-    __shared__ __attribute__((aligned(16))) int lds[LDSDW];
+    __shared__ __attribute__((aligned(16))) int lds[DecimLds<L, 2, PACK16>::dwords]; // the VALU pieces' stage buffers
     const int nleg = a.nstreams * a.mf_npieces;
     const int bx = blockIdx.x;
     if (bx < nleg) {
@@ -323,7 +331,7 @@ template <int L, bool PACK16> __global__ __launch_bounds__(NT, MF_WAVES) void de
     }
     const int gw = __builtin_amdgcn_readfirstlane((bx - nleg) * 4 + (int)(threadIdx.x >> 6));
     if (gw >= a.nstreams * a.mf_wps) return;
-    mf_wave<L>(a, gw, lds + (threadIdx.x >> 6) * (L * MF_RING_STAGE));
+    mf_wave<L>(a, gw);
 }
 
 template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream_t stream)
