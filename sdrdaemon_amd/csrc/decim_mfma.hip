@@ -101,7 +101,20 @@ template <int N, class F> __device__ __forceinline__ void mf_static_for(F &&f)
     mf_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-__device__ __forceinline__ int4_t mfma(int4_t a, int4_t b, int4_t c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
+#ifndef MF_ABL
+#define MF_ABL 0 // timing experiments (wrong results): 1 no MFMAs, 2 no recombination, 8 no limb packs, 16 no packs of the raw samples
+#endif
+__device__ __forceinline__ int4_t mfma(int4_t a, int4_t b, int4_t c)
+{
+#if MF_ABL & 1
+    asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+    return c;
+#elif MF_ABL & 32 // every MFMA twice
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0), 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+#endif
+}
 __device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
 template <int NS> struct MfState {
@@ -154,8 +167,14 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
         int4_t g1 = mfma(Ah0, st.O[0][1], z);
         int4_t g2 = mfma(Ah1, st.O[0][1], z);
         g1 = mfma(Ah1, st.O[0][0], g1);
+#if MF_ABL & 2
+        asm volatile("" ::"v"(g1), "v"(g2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (unsigned)g0[r];
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = lshl_add(opaque(lshl_add((unsigned)g2[r], 8, (unsigned)g1[r])), 8, (unsigned)g0[r]);
+#endif
     } else {
         const int4_t cN = {k.cinN, k.cinN, k.cinN, k.cinN};
         int4_t g0 = mfma(Ah0, st.O[S][0], cN);
@@ -164,17 +183,32 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
         int4_t g3 = mfma(Ah1, st.O[S][2], z);
         g1 = mfma(Ah1, st.O[S][0], g1);
         g2 = mfma(Ah1, st.O[S][1], g2);
+#if MF_ABL & 2
+        asm volatile("" ::"v"(g1), "v"(g2), "v"(g3));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (unsigned)g0[r];
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             acc[r] = lshl_add(opaque(lshl_add(opaque(lshl_add((unsigned)g3[r], 8, (unsigned)g2[r])), 8, (unsigned)g1[r])), 8, (unsigned)g0[r]);
+#endif
     }
 
+#if MF_ABL & 64 // two more shift-adds per output
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = lshl_add(opaque(lshl_add(opaque(acc[r]), 1, acc[r])), 2, acc[r]);
+#endif
     if constexpr (S < NS - 1) {
         // outputs 4q .. 4q+3 of this tile as 19-bit fields u = acc >>> 13 (limbs: bytes 0, 1 and bits 16-18).  r = 1, 3
         // are odd inputs of stage S+1 (entries 8 I + 2q, + 1 of its odd plane), r = 0, 2 the same entries of its even plane
         constexpr int SIG = I & 1, J = I >> 1;
         const unsigned X = 0x80808080u, X2 = 0x04040404u;
         const unsigned u0 = acc[0] >> 13, u1 = acc[1] >> 13, u2 = acc[2] >> 13, u3 = acc[3] >> 13;
+#if MF_ABL & 8
+        asm volatile("" : "+v"(st.O[S + 1][0]), "+v"(st.O[S + 1][1]), "+v"(st.O[S + 1][2]) : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
+        if constexpr (SIG == 1) mf_stage<NS, S + 1, J>(st, k, oc, comp);
+        return;
+#endif
         const unsigned po = perm(u3, u1, 0x05010400u), po2 = perm(u3, u1, 0x0c0c0602u);
         const unsigned pe = perm(u2, u0, 0x05010400u), pe2 = perm(u2, u0, 0x0c0c0602u);
         if constexpr (SIG == 0) {
@@ -220,11 +254,14 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
     constexpr int L = NS;
     constexpr int P = 4 << (NS - 1);    // first-stage steps per period
 #ifndef MF_DEPTH
-#define MF_DEPTH 4
+#define MF_DEPTH 8
+#endif
+#ifndef MF_BURST
+#define MF_BURST 1 // loads are issued for MF_BURST consecutive steps at a time (contiguous addresses per span)
 #endif
     constexpr int D = MF_DEPTH;         // steps of loads in flight
     constexpr size_t W = (size_t)64 << L; // warm-up = one period, raw samples
-    static_assert(P % D == 0, "prefetch ring");
+    static_assert(P % D == 0 && D % MF_BURST == 0, "prefetch ring");
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, q = lane >> 4, comp = n & 1, p = n >> 1;
     const int stream = gw / a.mf_wps, ws = gw - stream * a.mf_wps;
@@ -282,6 +319,9 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
     // end of the span, i.e. into the next span or (last span of a stream) the first 32 D samples of the tail that
     // plan_decimate_mfma() guarantees
     const char *src = wbase + loff;
+#ifdef MF_SKEW // experiment: de-phase the waves' addresses (wrong data)
+    src += (size_t)(gw % MF_SKEW) * (4096 / MF_SKEW);
+#endif
 #pragma unroll
     for (int d = 0; d < D; ++d) ld[d] = *reinterpret_cast<const uint4_t *>(src + 128 * d);
 
@@ -291,7 +331,15 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
             constexpr int i = decltype(ic)::value;
             constexpr int slot = i % D;
             const uint4_t r = ld[slot];
-            ld[slot] = *reinterpret_cast<const uint4_t *>(src + 128 * (i + D));
+            if constexpr ((i + 1) % MF_BURST == 0) {
+#pragma unroll
+                for (int b = MF_BURST - 1; b >= 0; --b) ld[(i - b) % D] = *reinterpret_cast<const uint4_t *>(src + 128 * (i - b + D));
+            }
+#if MF_ABL & 16
+            asm volatile("" : "+v"(st.O[0][0]), "+v"(st.O[0][1]) : "v"(r));
+            mf_stage<NS, 0, i>(st, k, oc, comp);
+            return;
+#endif
             // four samples x, y, z, w: y, w are odd-plane entries, x, z even-plane entries (2q, 2q + 1 of their half block)
             const unsigned ao = perm(r.w, r.y, sel_own), ae = perm(r.z, r.x, sel_own);
             const unsigned xo = perm(r.w, r.y, sel_oth), xe = perm(r.z, r.x, sel_oth);

@@ -22,7 +22,9 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(FrameArgs a)
     unsigned *dst = a.out + (size_t)stream * a.out_stride;
     const unsigned fdw = (unsigned)a.frame_blocks * 128u;
     // payload
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < a.n; k += (size_t)gridDim.x * 256) {
+    const size_t nskip = a.skip_to - a.skip_from, ncopy = a.n - nskip;
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < ncopy; j += (size_t)gridDim.x * 256) {
+        const size_t k = j < a.skip_from ? j : j + nskip;
         const uint64_t g = a.frame_sample_base + k;
         const uint64_t f = g / 16129u;
         const unsigned w = (unsigned)(g - f * 16129u);
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(FrameArgs a)
 
 hipError_t launch_frame_pack(const FrameArgs &a, int nstreams, hipStream_t stream)
 {
-    size_t blocks = (a.n + 255) / 256;
+    size_t blocks = (a.n - (a.skip_to - a.skip_from) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(frame_pack_kernel, dim3((unsigned)blocks, nstreams), dim3(256), 0, stream, a);

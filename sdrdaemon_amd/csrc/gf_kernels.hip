@@ -250,6 +250,19 @@ __global__ __launch_bounds__(GF_NT, 4) void gf_encode128_kernel(Enc128Args a) //
     const unsigned *src = reinterpret_cast<const unsigned *>(a.in + frc * a.in_frame_bytes) + 1 + (live ? col : 0);
     unsigned *dst = reinterpret_cast<unsigned *>(a.out + frc * a.out_frame_bytes) + 1 + (live ? col : 0);
     const unsigned hdr0 = (live && col == 0) ? src[-1] : 0u;
+    // fused framing: blocks 1..127 of this frame come straight from the decimated stream (127 samples each)
+    bool fused = false;
+    const unsigned *bsrc = src; // block b at bsrc[b * bstride]
+    int bstride = 128;
+    if (a.lin && live) {
+        const int s = fr / a.lin_cap, f = fr - s * a.lin_cap;
+        if (f >= a.lin_first) {
+            fused = true;
+            bsrc = a.lin + (size_t)s * a.lin_stride + ((size_t)f * 16129u - (size_t)a.lin_pending) + col - 127;
+            bstride = 127;
+        }
+    }
+    unsigned *fdst = const_cast<unsigned *>(src);
 
     const int npairs = (a.rows + 31) / 32; // pairs of 16-row tiles
 #pragma unroll 1
@@ -263,8 +276,14 @@ __global__ __launch_bounds__(GF_NT, 4) void gf_encode128_kernel(Enc128Args a) //
             const int cb = 2 * w + q;
             unsigned v[2 * KN - 1];
             if (live) {
+                // (block 0 = the meta block is never in the stream)
+                v[0] = (fused && cb == 0) ? src[0] : bsrc[(size_t)(KN * cb) * bstride];
 #pragma unroll
-                for (int i = 0; i < KN; ++i) v[i] = src[(size_t)(KN * cb + i) * 128];
+                for (int i = 1; i < KN; ++i) v[i] = bsrc[(size_t)(KN * cb + i) * bstride];
+                if (fused && tp == 0) {
+#pragma unroll
+                    for (int i = 0; i < KN; ++i) fdst[(size_t)(KN * cb + i) * 128] = v[i];
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < KN; ++i) v[i] = 0u;

@@ -14,11 +14,10 @@ using namespace sdrhip;
 namespace sdrhip {
 
 // below this many recovery blocks the generic kernel (rows x 128 products) is cheaper than a full
-// 32-row Karatsuba tile (13.7 k lane-ops per column vs 36 k x rows / 32)
-constexpr int ENC128_MIN_ROWS = 13;
+// 32-row Karatsuba tile (13.7 k lane-ops per column vs 36 k x rows / 32): ENC128_MIN_ROWS, sdrhip_internal.h
 
 int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
-                      size_t rec_frame_bytes, const int32_t *frame_list_dev, int ngroups)
+                      size_t rec_frame_bytes, const int32_t *frame_list_dev, int ngroups, const EncodeLin *lin)
 {
     if (nframes == 0 || nb_fec <= 0) return SDRHIP_OK;
     hipError_t e;
@@ -31,6 +30,7 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
         k.in_frame_bytes = frame_bytes; k.out_frame_bytes = rec_frame_bytes;
         k.rows = nb_fec; k.nframes = (int)nframes;
         k.frame_list = frame_list_dev; k.nlist = frame_list_dev ? ngroups * GF_FRAMES_PER_GROUP : (int)nframes;
+        if (lin) { k.lin = lin->lin; k.lin_stride = lin->stride; k.lin_cap = lin->cap; k.lin_first = lin->first; k.lin_pending = lin->pending; }
         {
             KTimer kt(c, SDRHIP_K_FEC_ENCODE);
             e = launch_gf_encode128(k, c->stream);

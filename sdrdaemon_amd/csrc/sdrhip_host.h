@@ -72,8 +72,17 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
 // frames/recovery on the device; recovery slots may be interleaved with the frames
 // (rec_frame_bytes = stride between the recovery areas of consecutive frames)
 // frame_list_dev (optional, device): groups of GF_FRAMES_PER_GROUP frame indices (-1 = none), ngroups of them
+// lin (optional, Rx pipe): the payload of the frame slots >= first of every stream is taken from the stream-order output
+// of the decimator and copied into the frame area by the encoder itself (Enc128Args::lin); only honoured when the
+// structured encoder runs (nb_fec >= ENC128_MIN_ROWS): the caller checks fec_encode_fuses_framing()
+struct EncodeLin {
+    const unsigned *lin;
+    size_t stride;
+    int cap, first, pending;
+};
+inline bool fec_encode_fuses_framing(int nb_fec) { return nb_fec >= sdrhip::ENC128_MIN_ROWS; }
 int fec_encode_device(sdrhip_ctx *ctx, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
-                      size_t rec_frame_bytes, const int32_t *frame_list_dev = nullptr, int ngroups = 0);
+                      size_t rec_frame_bytes, const int32_t *frame_list_dev = nullptr, int ngroups = 0, const EncodeLin *lin = nullptr);
 // rx on the device, indices on the host; payload_out / block0_out on the device
 int fec_decode_device(sdrhip_ctx *ctx, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
                       uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out);

@@ -84,6 +84,7 @@ struct FrameArgs {
     unsigned *out;        // frame area: stream s at out + s * out_stride dwords, slot 0 = the frame being filled
     size_t in_stride, out_stride;
     size_t n;             // samples per stream in this call
+    size_t skip_from, skip_to;  // samples [skip_from, skip_to) are not copied (the encoder moves them, Enc128Args::lin)
     uint64_t frame_sample_base; // samples already in slot 0
     int frame_blocks;     // super blocks per frame slot (128 + nb_fec)
     int meta_first, meta_count; // as DecimArgs::meta_*
@@ -147,7 +148,16 @@ struct Enc128Args {
     int nframes;                    // frames addressable through in/out
     const int32_t *frame_list;      // optional list of frame indices (-1 = skip), nlist entries; NULL = 0..nlist-1
     int nlist;
+    // Rx pipe behind a stream-order decimator: the payload of super blocks 1..127 of frame slot f >= lin_first of stream s
+    // (frame index s * lin_cap + f) is taken from lin[s][f * 16129 - lin_pending ...] instead of the frame area, and
+    // written into the frame area on the way (UDPSinkFEC::write's copy, UDPSinkFEC.cpp:134-155, fused into the encoder);
+    // block 0 and the headers are in place already.  lin == NULL: plain encode.
+    const unsigned *lin;
+    size_t lin_stride;              // dwords between streams
+    int lin_cap, lin_first, lin_pending;
 };
+// smallest number of recovery blocks the structured 128-original encoder is used for (below: the generic matrix kernel)
+constexpr int ENC128_MIN_ROWS = 13;
 hipError_t launch_gf_encode128(const Enc128Args &a, hipStream_t stream);
 hipError_t launch_block_scatter(const uint8_t *src, size_t src_frame_bytes, int src_pitch, int src_off, uint8_t *dst,
                                 size_t dst_frame_bytes, int dst_pitch, int dst_off, const int16_t *map, int nblocks, int nframes,

@@ -315,6 +315,8 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     }
 
     size_t n_out = 0;
+    EncodeLin elin;
+    bool use_lin = false;
     const bool filterless = L == 0 || (rx->cfg.fcpos != SDRHIP_FC_CEN && L <= 2); // Decimators.cpp:22-91,127-170: no cascade kernel
     if (filterless || decimate_mfma_applies(rx->dec, L, rx->cfg.fcpos, n_in)) {
         // ---- decimate in stream order, then K2 lays the samples out as super blocks (+ meta blocks and headers)
@@ -322,8 +324,22 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         if ((rc = rx->lin.reserve((size_t)S * lstride * 4 + 16))) return rc;
         rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, rx->lin.as<int16_t>(), lstride, &n_out, 0, 0, 0, nullptr);
         if (rc) return rc;
+        // the frames that lie entirely inside this call's samples are laid out by the encoder (fused copy); K2 does
+        // the frame that was open when the call began, the one left open at its end, meta blocks and headers
+        if (fec_encode_fuses_framing(R)) {
+            const size_t first = rx->pending_samples ? 1 : 0;
+            if (done > first && frame_bytes % 4 == 0) {
+                elin.lin = rx->lin.as<unsigned>(); elin.stride = lstride; elin.cap = (int)rx->cap_frames;
+                elin.first = (int)first; elin.pending = (int)rx->pending_samples;
+                use_lin = true;
+            }
+        }
         FrameArgs fa;
         memset(&fa, 0, sizeof(fa));
+        if (use_lin) {
+            fa.skip_from = (size_t)elin.first * SDRHIP_SAMPLES_PER_FRAME - (size_t)elin.pending;
+            fa.skip_to = done * SDRHIP_SAMPLES_PER_FRAME - (size_t)elin.pending;
+        }
         fa.in = rx->lin.as<unsigned>(); fa.out = reinterpret_cast<unsigned *>(work);
         fa.in_stride = lstride; fa.out_stride = stream_bytes / 4;
         fa.n = n_dec; fa.frame_sample_base = rx->pending_samples; fa.frame_blocks = FB;
@@ -352,7 +368,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
             rx->flist_done = done; rx->flist_cap = rx->cap_frames;
         }
         if ((rc = fec_encode_device(c, work, frame_bytes, (size_t)S * rx->cap_frames, R, work + (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE,
-                                    frame_bytes, rx->flist.as<int32_t>(), (int)(rx->flist_host.size() / GF_FRAMES_PER_GROUP))))
+                                    frame_bytes, rx->flist.as<int32_t>(), (int)(rx->flist_host.size() / GF_FRAMES_PER_GROUP), use_lin ? &elin : nullptr)))
             return rc;
     }
     if (done && frames_out)

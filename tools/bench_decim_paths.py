@@ -24,7 +24,7 @@ n = 1 << LOGN
 x = torch.randint(-32768, 32768, (S, n, 2), generator=g, device=dev, dtype=torch.int16)
 
 
-def timed(fn, reps=30, preroll_s=0.25):
+def timed(fn, reps=int(os.environ.get("REPS", "30")), preroll_s=0.25):
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < preroll_s:
         fn()
