@@ -2,6 +2,7 @@
 #include "gf256.h"
 #include "sdrhip_host.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -74,11 +75,22 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
     a.in = in; a.out = out; a.in_stride = in_stride; a.out_stride = out_stride; a.n_in = n_in;
     a.state_cur = p->state[p->cur]; a.state_next = p->state[p->cur ^ 1];
     a.nstreams = p->nstreams;
-    plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
+    // SDRHIP_INTERP_PATH=mfma selects the matrix-core cascade (interp_mfma.hip, DESIGN.md "K5m": bit-exact but slower
+    // than the VALU kernel, kept as a measured experiment); SDRHIP_INTERP_SPAN = span length in inputs (tests)
+    bool use_mfma = false;
+    if (const char *pe = getenv("SDRHIP_INTERP_PATH")) {
+        if (!strcmp(pe, "mfma")) {
+            size_t span = 0;
+            if (const char *v = getenv("SDRHIP_INTERP_SPAN")) span = (size_t)strtoull(v, nullptr, 10);
+            use_mfma = plan_interpolate_mfma(log2interp, n_in, p->nstreams, span, &a);
+        }
+    }
+    if (!use_mfma) plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
+    a.mf_dump = c->decim_dump;
     hipError_t e;
     {
         KTimer kt(c, SDRHIP_K_INTERPOLATE);
-        e = launch_interpolate(log2interp, a, c->stream);
+        e = use_mfma ? launch_interpolate_mfma(log2interp, a, c->stream) : launch_interpolate(log2interp, a, c->stream);
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "interpolate launch: %s", hipGetErrorString(e));
     p->cur ^= 1;
