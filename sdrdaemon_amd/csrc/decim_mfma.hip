@@ -259,9 +259,9 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
 #ifndef MF_BURST
 #define MF_BURST 1 // loads are issued for MF_BURST consecutive steps at a time (contiguous addresses per span)
 #endif
-    constexpr int D = MF_DEPTH;         // steps of loads in flight
+    constexpr int D = MF_DEPTH < P ? MF_DEPTH : P / 2; // steps of loads in flight
     constexpr size_t W = (size_t)64 << L; // warm-up = one period, raw samples
-    static_assert(P % D == 0 && D % MF_BURST == 0, "prefetch ring");
+    static_assert(P % D == 0, "prefetch ring");
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, q = lane >> 4, comp = n & 1, p = n >> 1;
     const int stream = gw / a.mf_wps, ws = gw - stream * a.mf_wps;
@@ -322,6 +322,9 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
 #ifdef MF_SKEW // experiment: de-phase the waves' addresses (wrong data)
     src += (size_t)(gw % MF_SKEW) * (4096 / MF_SKEW);
 #endif
+    // (Tried: loads and s_waitcnt vmcnt(D - 1) issued by hand in asm, because hipcc, which counts outstanding VMEM
+    // operations exactly only inside a basic block, drains the ring with a vmcnt(0) at the top of every period: same
+    // launch time, 0.255 ms both ways, and the register allocator may copy an asm load's destination before the wait.)
 #pragma unroll
     for (int d = 0; d < D; ++d) ld[d] = *reinterpret_cast<const uint4_t *>(src + 128 * d);
 
@@ -331,10 +334,7 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
             constexpr int i = decltype(ic)::value;
             constexpr int slot = i % D;
             const uint4_t r = ld[slot];
-            if constexpr ((i + 1) % MF_BURST == 0) {
-#pragma unroll
-                for (int b = MF_BURST - 1; b >= 0; --b) ld[(i - b) % D] = *reinterpret_cast<const uint4_t *>(src + 128 * (i - b + D));
-            }
+            ld[slot] = *reinterpret_cast<const uint4_t *>(src + 128 * (i + D));
 #if MF_ABL & 16
             asm volatile("" : "+v"(st.O[0][0]), "+v"(st.O[0][1]) : "v"(r));
             mf_stage<NS, 0, i>(st, k, oc, comp);
