@@ -396,7 +396,7 @@ template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream
 
 bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, size_t span_override, DecimArgs *a)
 {
-    if (fcpos != 2 || log2decim < 2 || log2decim > 4) return false;
+    if (fcpos != 2 || log2decim < 2 || log2decim > 6) return false;
     const size_t W = (size_t)64 << log2decim;     // one period of the schedule = the warm-up
     const size_t head = W > 2048 ? W : 2048;      // VALU head piece: whole passes, >= the warm-up of the first span
     if (n_used <= head) return false;
@@ -405,10 +405,11 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
     if (span_override) {
         S = (span_override + W - 1) / W * W;
     } else {
-        // one round of three waves per SIMD (the kernel's 160 VGPRs admit three 4-wave workgroups per CU; the VALU
-        // pieces take a few of the 768 slots): ~2900 waves of 8 spans when the call is big enough, longer spans
-        // beyond; at least 8 warm-ups per span (<= 12 % overhead)
-        S = (n * (size_t)nstreams / (2900 * 8) + W - 1) / W * W;
+        // one round of three waves per SIMD (the kernel's 164 VGPRs admit three 4-wave workgroups per CU; the VALU
+        // pieces take a few of the 768 slots; L = 5: 179 VGPRs, two per CU): ~2900 / ~1950 waves of 8 spans when the
+        // call is big enough, longer spans beyond; at least 8 warm-ups per span (<= 12 % overhead)
+        const size_t round = log2decim >= 5 ? 1950 : 2900;
+        S = (n * (size_t)nstreams / (round * 8) + W - 1) / W * W;
         if (S < 8 * W) S = 8 * W;
         if (S > 256 * W) S = 256 * W;
     }
@@ -439,6 +440,8 @@ hipError_t launch_decimate_mfma(int log2decim, bool pack16, const DecimArgs &a, 
     case 2: return launch_mf<2>(pack16, a, stream);
     case 3: return launch_mf<3>(pack16, a, stream);
     case 4: return launch_mf<4>(pack16, a, stream);
+    case 5: return launch_mf<5>(pack16, a, stream);
+    case 6: return launch_mf<6>(pack16, a, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -44,7 +44,7 @@ def test_mfma_vs_oracle_all_signals(ctx, oracle, mfma_path, signal):
 
     x = signals.ALL[signal](300000 + 77)
     for bias in (0, 1):
-        for log2 in (4, 3, 2):
+        for log2 in (6, 5, 4, 3, 2):
             d, od = sd.Decimators(ctx, 1, bias), oracle.decimators(bias)
             for seg in (x[:200001], x[200001:]):
                 a, sa = d.decimate(log2, 2, 16, seg)

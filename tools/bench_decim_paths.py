@@ -37,7 +37,7 @@ def timed(fn, reps=int(os.environ.get("REPS", "30")), preroll_s=0.25):
     return ms / max(cnt, 1)
 
 
-for L in (4, 3, 2) if ONLY is None else (int(ONLY[2]),):
+for L in (6, 5, 4, 3, 2) if ONLY is None else (int(ONLY[2]),):
     out = torch.empty((S, n >> L, 2), dtype=torch.int16, device=dev)
     ref = None
     for path, span in ((("valu", 0), ("mfma", 0), ("mfma", 8192), ("mfma", 16384), ("mfma", 32768), ("mfma", 65536)) if ONLY is None
