@@ -89,18 +89,21 @@ def test_mfma_stream_bank(ctx, oracle, mfma_path):
         assert np.array_equal(y[s], b), s
 
 
-def test_mfma_rx_pipe_frames(ctx, oracle, mfma_path):
-    """Fused Rx pipe: the matrix-core waves scatter straight into the super blocks (UDPSinkFEC::write layout)."""
+@pytest.mark.parametrize("nb_fec", [8, 32])
+def test_mfma_rx_pipe_frames(ctx, oracle, mfma_path, nb_fec):
+    """Rx pipe behind the matrix-core decimator: stream-order output, then UDPSinkFEC::write's layout by the framing
+    kernel (nb_fec = 8: generic encoder) or by the 128-original encoder itself (nb_fec = 32: only the frame open at
+    either end of a call goes through the framing kernel); three ragged calls, frames spanning calls."""
     import sdrdaemon_amd as sd
 
     for span in (1024, 8192):
         mfma_path(span)
-        nsamp = (3 * 16129 + 5000) << 4
+        nsamp = (5 * 16129 + 5000) << 4
         x = signals.noise(nsamp, 31, 16)
-        rx = sd.RxPipe(ctx, 1, log2decim=4, fcpos=sd.FC_CEN, hb_variant=0, sample_bits=16, nb_fec=8,
+        rx = sd.RxPipe(ctx, 1, log2decim=4, fcpos=sd.FC_CEN, hb_variant=0, sample_bits=16, nb_fec=nb_fec,
                        center_frequency_khz=435000, sample_rate=625000)
         od = oracle.decimators(0)
-        fr = oracle.framer(nb_fec_blocks=8)
+        fr = oracle.framer(nb_fec_blocks=nb_fec)
         cuts = [0, nsamp // 3 + 80, nsamp // 3 + 80 + 16 * 1000, nsamp]
         got, exp = [], []
         for i in range(3):
@@ -110,7 +113,7 @@ def test_mfma_rx_pipe_frames(ctx, oracle, mfma_path):
             fr.s.tv_sec, fr.s.tv_usec = 100 + i, 7 * i
             exp.append(fr.write(y))
         got, exp = np.concatenate(got), np.concatenate(exp)
-        assert got.shape[0] == exp.shape[0] == 3
-        for f in range(3):
+        assert got.shape[0] == exp.shape[0] == 5
+        for f in range(5):
             assert np.array_equal(got[f, :128], exp[f]), (span, f)
-            assert np.array_equal(got[f, 128:], oracle.frame_encode(exp[f], 8)), (span, f)
+            assert np.array_equal(got[f, 128:], oracle.frame_encode(exp[f], nb_fec)), (span, f)
