@@ -405,11 +405,14 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
     if (span_override) {
         S = (span_override + W - 1) / W * W;
     } else {
-        // one round of three waves per SIMD (the kernel's 164 VGPRs admit three 4-wave workgroups per CU; the VALU
-        // pieces take a few of the 768 slots; L = 5: 179 VGPRs, two per CU): ~2900 / ~1950 waves of 8 spans when the
-        // call is big enough, longer spans beyond; at least 8 warm-ups per span (<= 12 % overhead)
-        const size_t round = log2decim >= 5 ? 1950 : 2900;
+        // waves in flight: one round of three per SIMD for the short cascades (164 VGPRs admit three 4-wave workgroups per
+        // CU; the VALU pieces take a few of the 768 slots), ONE per SIMD from decimate16 up: with four and more stages
+        // per step a single wave keeps its SIMD as busy as three do (measured, tools/sweep_span.sh), and spans three times
+        // as long cost a third of the warm-up (3 % instead of 9 %); never more waves than SIMDs then, a second round
+        // would double the time.  decimate64: two per SIMD (193 VGPRs; its warm-up is 4096 samples).
+        const size_t round = log2decim <= 3 ? 2900 : (log2decim == 6 ? 2048 : 1024);
         S = (n * (size_t)nstreams / (round * 8) + W - 1) / W * W;
+        if (S > 256 * W) S = (n * (size_t)nstreams / (2900 * 8) + W - 1) / W * W; // too big for one wave per SIMD: three
         if (S < 8 * W) S = 8 * W;
         if (S > 256 * W) S = 256 * W;
     }
