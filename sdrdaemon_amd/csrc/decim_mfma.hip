@@ -358,15 +358,19 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
     }
 }
 
-// grid.x = nstreams * mf_npieces VALU workgroups (head + tail pieces of every stream), then the matrix-core
-// workgroups (four waves = four groups of 8 spans each)
+// grid.x = the matrix-core workgroups (four waves = four groups of 8 spans each), then nstreams * mf_npieces VALU
+// workgroups (head + tail pieces of every stream)
 template <int L, bool PACK16> __global__ __launch_bounds__(NT, MF_WAVES) void decim_mfma_kernel(DecimArgs a)
 {
     __shared__ __attribute__((aligned(16))) int lds[DecimLds<L, 2, PACK16>::dwords]; // the VALU pieces' stage buffers
-    const int nleg = a.nstreams * a.mf_npieces;
+    // The matrix-core workgroups come FIRST in the grid: the dispatcher deals the first workgroups of a launch across
+    // the empty CUs, and with one wave per SIMD (plan_decimate_mfma) the launch takes as long as its fullest CU: a CU
+    // that got two of them while the short VALU pieces held slots elsewhere doubled the time of the whole launch.
+    const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
     const int bx = blockIdx.x;
-    if (bx < nleg) {
-        const int stream = bx / a.mf_npieces, piece = bx - stream * a.mf_npieces;
+    if (bx >= nmf) {
+        const int lx = bx - nmf;
+        const int stream = lx / a.mf_npieces, piece = lx - stream * a.mf_npieces;
         if (piece == 0) {
             decim_piece<L, 2, PACK16>(a, lds, stream, 0, a.mf_head, true, false, piece, a.mf_npieces);
         } else {
@@ -377,7 +381,7 @@ template <int L, bool PACK16> __global__ __launch_bounds__(NT, MF_WAVES) void de
         }
         return;
     }
-    const int gw = __builtin_amdgcn_readfirstlane((bx - nleg) * 4 + (int)(threadIdx.x >> 6));
+    const int gw = __builtin_amdgcn_readfirstlane(bx * 4 + (int)(threadIdx.x >> 6));
     if (gw >= a.nstreams * a.mf_wps) return;
     mf_wave<L>(a, gw);
 }
@@ -405,14 +409,28 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
     if (span_override) {
         S = (span_override + W - 1) / W * W;
     } else {
-        // waves in flight: one round of three per SIMD for the short cascades (164 VGPRs admit three 4-wave workgroups per
-        // CU; the VALU pieces take a few of the 768 slots), ONE per SIMD from decimate16 up: with four and more stages
-        // per step a single wave keeps its SIMD as busy as three do (measured, tools/sweep_span.sh), and spans three times
-        // as long cost a third of the warm-up (3 % instead of 9 %); never more waves than SIMDs then, a second round
-        // would double the time.  decimate64: two per SIMD (193 VGPRs; its warm-up is 4096 samples).
-        const size_t round = log2decim <= 3 ? 2900 : (log2decim == 6 ? 2048 : 1024);
-        S = (n * (size_t)nstreams / (round * 8) + W - 1) / W * W;
-        if (S > 256 * W) S = (n * (size_t)nstreams / (2900 * 8) + W - 1) / W * W; // too big for one wave per SIMD: three
+        const size_t total = n * (size_t)nstreams;
+        if (log2decim <= 3) {
+            // short cascades: one round of three waves per SIMD (164 VGPRs admit three 4-wave workgroups per CU; the VALU
+            // pieces take a few of the 768 slots), longer spans beyond; measured best for decimate4 / 8
+            S = (total / (2900 * 8) + W - 1) / W * W;
+        } else {
+            // decimate16 and up: with four and more stages per step a single wave keeps its SIMD as busy as three do
+            // (tools/sweep_span.sh, tools/bench_streams.sh), so the spans can be long and the warm-up small (3 % at 32 Ki
+            // samples and L = 4 against the 9 % of a three-waves-per-SIMD round).  One wave per SIMD: 31 workgroups per XCD
+            // (992 waves; with all 32 CUs of an XCD taken -- 1016 waves -- the launch is 3 % slower, with 1056 it takes
+            // half as long again: the launch lasts as long as its fullest CU), the spans as long as that allows, sized
+            // from the wave count so that the VALU tail stays short.  Banks too big for that (spans beyond the limit of
+            // the planner): spans of 32 Ki samples, the waves are dealt dynamically over many rounds.
+            const size_t SL = 32768 > 8 * W ? 32768 : 8 * W;
+            const size_t wps1 = 992 / (size_t)nstreams;
+            S = SL;
+            if (wps1 >= 1) {
+                size_t S1 = n / (8 * wps1) / W * W;
+                if (S1 == 0 || n / (8 * S1) > wps1) S1 += W; // (rounding down must not add a wave)
+                if (S1 <= 256 * W) S = S1;
+            }
+        }
         if (S < 8 * W) S = 8 * W;
         if (S > 256 * W) S = 256 * W;
     }
