@@ -431,7 +431,9 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
                 if (S1 <= 256 * W) S = S1;
             }
         }
-        if (S < 8 * W) S = 8 * W;
+        // small calls: short spans (the launch lasts (W + S) / 32 steps of ~0.2 us whatever the size of the call)
+        const size_t smin = (log2decim <= 3 ? 8 : 2) * W;
+        if (S < smin) S = smin;
         if (S > 256 * W) S = 256 * W;
     }
     size_t wps = n / (8 * S);

@@ -297,6 +297,10 @@ DecimPathEnv decim_path_env()
     if (const char *p = getenv("SDRHIP_MFMA_MIN")) e.min_samples = (size_t)strtoull(p, nullptr, 10);
     return e;
 }
+// A launch of the matrix-core kernel lasts at least one warm-up + the shortest span, i.e. ~20 us at decimate16 and
+// twice as long per further stage, however small the call; below these sizes the VALU kernel is faster
+// (tools/bench_small.py): 2^22 samples over all streams up to decimate8, 2^23 for decimate16, 2^24, 2^25.
+size_t mfma_min_samples(const DecimPathEnv &e, int log2decim) { return e.min_samples << (log2decim > 3 ? log2decim - 3 : 0); }
 } // namespace
 
 namespace sdrhip {
@@ -352,7 +356,7 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     // SDRHIP_DECIM_PATH = valu | mfma | auto (default), SDRHIP_MFMA_SPAN = span length in samples (tests)
     const DecimPathEnv env = decim_path_env(); // (read per call: tests switch paths inside one process)
     bool use_mfma = false;
-    if (!frame_mode && env.path != DECIM_PATH_VALU && (env.path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= env.min_samples))
+    if (!frame_mode && env.path != DECIM_PATH_VALU && (env.path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= mfma_min_samples(env, (int)L)))
         use_mfma = plan_decimate_mfma((int)L, fcpos, a.n_used, d->nstreams, env.span, &a);
     a.mf_dump = c->decim_dump;
     hipError_t e;
@@ -377,7 +381,7 @@ bool decimate_mfma_applies(const sdrhip_decimators *d, int log2decim, int fcpos,
 {
     const DecimPathEnv env = decim_path_env();
     const size_t n_used = (n_in >> log2decim) << log2decim;
-    if (env.path == DECIM_PATH_VALU || (env.path != DECIM_PATH_MFMA && n_used * (size_t)d->nstreams < env.min_samples)) return false;
+    if (env.path == DECIM_PATH_VALU || (env.path != DECIM_PATH_MFMA && n_used * (size_t)d->nstreams < mfma_min_samples(env, log2decim))) return false;
     DecimArgs tmp;
     return plan_decimate_mfma(log2decim, fcpos, n_used, d->nstreams, env.span, &tmp);
 }
