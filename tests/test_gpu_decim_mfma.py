@@ -89,6 +89,32 @@ def test_mfma_stream_bank(ctx, oracle, mfma_path):
         assert np.array_equal(y[s], b), s
 
 
+@pytest.mark.parametrize("nstreams", [1, 3, 40])
+def test_mfma_default_span_planning_equals_valu(ctx, mfma_path, nstreams):
+    """The planner's own span choice (one wave per SIMD from decimate16 up, short spans for small calls, banks of many
+    streams) against the VALU kernel, two calls each so that the bank state crosses paths."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    os.environ.pop("SDRHIP_MFMA_SPAN", None)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3 + nstreams)
+    for n in ((70000, 300000 + 12) if nstreams > 3 else (70000, 300000 + 12, (1 << 21) + 76)):
+        x = torch.randint(-32768, 32768, (nstreams, n, 2), generator=g, device=dev, dtype=torch.int16)
+        for log2 in (2, 4, 5, 6):
+            res = []
+            for path in ("mfma", "valu"):
+                os.environ["SDRHIP_DECIM_PATH"] = path
+                d = sd.Decimators(ctx, nstreams, 0)
+                cut = (n // 2 + 8) & ~3  # (device rows must stay 16-byte aligned)
+                a, _ = d.decimate(log2, 2, 16, x[:, :cut])
+                b, _ = d.decimate(log2, 2, 16, x[:, cut:])
+                res.append((a.clone(), b.clone()))
+            ctx.synchronize()
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (nstreams, n, log2)
+
+
 @pytest.mark.parametrize("nb_fec", [8, 32])
 def test_mfma_rx_pipe_frames(ctx, oracle, mfma_path, nb_fec):
     """Rx pipe behind the matrix-core decimator: stream-order output, then UDPSinkFEC::write's layout by the framing
