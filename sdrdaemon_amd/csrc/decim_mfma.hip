@@ -156,9 +156,18 @@ __device__ __forceinline__ unsigned opaque(unsigned v)
     return v;
 }
 
+// decimate32 / 64: the windows of the last one / two stages are shifted with moves (six per tile, of stages that run every
+// 16 and 32 steps) instead of rotating in place: their phase then is a constant and the unrolled schedule repeats after
+// 32 steps like decimate16's, a half / a quarter of the code (decimate64: ~20 KB instead of ~80 KB, which did not fit the
+// instruction cache).
+__host__ __device__ constexpr int mf_nfixed(int ns) { return ns > 4 ? ns - 4 : 0; }
+__host__ __device__ constexpr bool mf_fixed(int ns, int s) { return s >= ns - mf_nfixed(ns); } // stage s of ns has a fixed window
+template <int NS> constexpr int mf_period() { return 4 << (NS - 1 - mf_nfixed(NS)); } // first-stage steps per period
+
 template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState<NS> &st, const MfConst &k, MfOut &oc, int comp)
 {
-    constexpr int PH = I & 3;
+    // (the last stages of the long cascades keep their windows in fixed dwords, see mf_nfixed)
+    constexpr int PH = mf_fixed(NS, S) ? 0 : (I & 3);
     const int4_t Ah0 = k.A[0][PH], Ah1 = k.A[1][PH];
     const int4_t z = {0, 0, 0, 0};
     unsigned acc[4];
@@ -215,13 +224,19 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
             st.pend[S + 1][0] = po; st.pend[S + 1][1] = po2;
             // this tile's first even output (lanes q = 0) is entry 16 J of the even plane: the last one tile J of the
             // next stage needs; the other 15 are in place since the previous block was completed (below)
-            constexpr int DJ = (J + 1) & 3;
+            constexpr int DJ = mf_fixed(NS, S + 1) ? 1 : ((J + 1) & 3);
             st.O[S + 1][0][DJ] = (int)(perm(pe, (unsigned)st.O[S + 1][0][DJ], k.selA) ^ X);
             st.O[S + 1][1][DJ] = (int)(perm(pe, (unsigned)st.O[S + 1][1][DJ], k.selB) ^ X);
             st.O[S + 1][2][DJ] = (int)(perm(pe2, (unsigned)st.O[S + 1][2][DJ], k.selA) ^ X2);
             st.evp[S + 1][0] = pe; st.evp[S + 1][1] = pe2;
         } else {
-            constexpr int NJ = J & 3, DN = (J + 2) & 3;
+            constexpr bool FIX = mf_fixed(NS, S + 1);
+            constexpr int NJ = FIX ? 0 : (J & 3), DN = FIX ? 1 : ((J + 2) & 3);
+            if constexpr (FIX) {
+                // phase 0 for ever: dword 0 = newest block, 3 = the previous one, 2 = the one before, 1 = the even entries
+#pragma unroll
+                for (int l = 0; l < 3; ++l) { st.O[S + 1][l][2] = st.O[S + 1][l][3]; st.O[S + 1][l][3] = st.O[S + 1][l][0]; }
+            }
             st.O[S + 1][0][NJ] = (int)(perm(po, st.pend[S + 1][0], 0x05040100u) ^ X);
             st.O[S + 1][1][NJ] = (int)(perm(po, st.pend[S + 1][0], 0x07060302u) ^ X);
             st.O[S + 1][2][NJ] = (int)(perm(po2, st.pend[S + 1][1], 0x05040100u) ^ X2);
@@ -252,7 +267,7 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
 template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw)
 {
     constexpr int L = NS;
-    constexpr int P = 4 << (NS - 1);    // first-stage steps per period
+    constexpr int P = mf_period<NS>();  // first-stage steps per period of the unrolled schedule
 #ifndef MF_DEPTH
 #define MF_DEPTH 8
 #endif
@@ -260,7 +275,8 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
 #define MF_BURST 1 // loads are issued for MF_BURST consecutive steps at a time (contiguous addresses per span)
 #endif
     constexpr int D = MF_DEPTH < P ? MF_DEPTH : P / 2; // steps of loads in flight
-    constexpr size_t W = (size_t)64 << L; // warm-up = one period, raw samples
+    constexpr size_t W = (size_t)64 << L; // warm-up, raw samples: one, two or four periods
+    constexpr int WP = (int)(W / (32 * (size_t)P));
     static_assert(P % D == 0, "prefetch ring");
     const int lane = threadIdx.x & 63;
     const int n = lane & 15, q = lane >> 4, comp = n & 1, p = n >> 1;
@@ -329,7 +345,7 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
     for (int d = 0; d < D; ++d) ld[d] = *reinterpret_cast<const uint4_t *>(src + 128 * d);
 
     for (int per = 0; per < nper; ++per) {
-        oc.store = per > 0;
+        oc.store = per >= WP;
         mf_static_for<P>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int slot = i % D;
