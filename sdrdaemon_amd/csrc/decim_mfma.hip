@@ -427,9 +427,16 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
     } else {
         const size_t total = n * (size_t)nstreams;
         if (log2decim <= 3) {
-            // short cascades: one round of three waves per SIMD (164 VGPRs admit three 4-wave workgroups per CU; the VALU
-            // pieces take a few of the 768 slots), longer spans beyond; measured best for decimate4 / 8
+            // short cascades (decimate4 / 8): TWO waves per SIMD, 62 workgroups per XCD (1984 waves), the spans sized from
+            // the wave count like below (tools/sweep_span.sh: 0.238 / 0.262 ms per 2^28 samples against 0.248 / 0.271 with
+            // one round of three waves per SIMD, 0.250 / 0.318 with one wave per SIMD); three per SIMD for bigger banks
             S = (total / (2900 * 8) + W - 1) / W * W;
+            const size_t wps2 = 1984 / (size_t)nstreams;
+            if (wps2 >= 1) {
+                size_t S2 = n / (8 * wps2) / W * W;
+                if (S2 == 0 || n / (8 * S2) > wps2) S2 += W; // (rounding down must not add a wave)
+                if (S2 <= 256 * W && S2 >= 8 * W) S = S2;
+            }
         } else {
             // decimate16 and up: with four and more stages per step a single wave keeps its SIMD as busy as three do
             // (tools/sweep_span.sh, tools/bench_streams.sh), so the spans can be long and the warm-up small (3 % at 32 Ki
