@@ -51,6 +51,12 @@ def make_input(ctx, device, n, seeds, kind):
     """-> (len(seeds), n, 2) int16 on the device.  noise: uniform full-scale int16 (the stress input of BASELINE.md 3.4,
     worst case for toggling); testsource: the library's TestSource bank (10 Msps, -20 dB CW at +100 kHz + 1 kHz per
     stream id: TestSource.cpp:59-215 semantics, README.md:362 signal), generated on the device."""
+    if kind == "hash":
+        # counter-based full-scale uniform noise (tests/signals.py): the stream the committed whole-output digests of the
+        # compiled reference were made from (tests/golden/headline_golden.json) -- see verify_step()
+        import signals
+
+        return torch.stack([signals.hash_noise_torch(n, seed, device) for seed in seeds])
     if kind == "noise":
         out = []
         for seed in seeds:
@@ -67,17 +73,19 @@ def make_input(ctx, device, n, seeds, kind):
     return x.reshape(len(seeds), n, 2).contiguous()
 
 
-def decim_kernel_name():
-    """the kernel sdrhip_decimate / sdrhip_rx_process run for decimate16_cen at this size (sdrhip.cpp: SDRHIP_DECIM_PATH)"""
-    return "decim_kernel<4,2,true>" if os.environ.get("SDRHIP_DECIM_PATH", "auto") == "valu" else "decim_mfma_kernel<4,true>"
+def decim_kernel_name(plan):
+    """the kernel the library actually launched for decimate16_cen (sdrhip_decimators_last_plan / sdrhip_rx_last_plan)"""
+    if plan.get("fused"):
+        return "rx_fused_kernel<4,true>"
+    return {"valu": "decim_kernel<4,2,true>", "mfma": "decim_mfma_kernel<4,true>"}.get(plan["path"], "none")
 
 
-def pmc_traffic(samples_per_launch):
+def pmc_traffic(samples_per_launch, kernel):
     """HBM bytes per launch of the decimator kernel from the committed PMC passes (profiles/traffic.json,
     collected with tools/prof.sh on this very command); None when the launch geometry differs."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f)[decim_kernel_name()]
+            t = json.load(f)[kernel]
         if int(t["samples_per_launch"]) != int(samples_per_launch):
             return None
         return float(t["fetch_size_kb"]) * 1024.0 * float(t["fetch_correction"]) + float(t["write_size_kb"]) * 1024.0
@@ -89,11 +97,11 @@ VALU_PEAK_TLANEOPS = 1024 * 16 * 2.4e9 / 1e12  # 1024 SIMDs x 16 lanes / clk x 2
 # (mad / dot2 / perm, 62 % of K1's mix; plain add / xor / shift issue faster: tools/valu_peak.hip)
 
 
-def pmc_valu_lane_ops(samples_per_launch):
+def pmc_valu_lane_ops(samples_per_launch, kernel):
     """integer VALU lane-ops per launch of the decimator kernel (SQ_INSTS_VALU x 64, committed PMC pass)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f)[decim_kernel_name()]
+            t = json.load(f)[kernel]
         if int(t["samples_per_launch"]) != int(samples_per_launch):
             return None
         return float(t["valu_wave_insts"]) * 64.0
@@ -222,7 +230,7 @@ def extra_configs(ctx, dev, x, kind):
     wall, per = timed_steps(ctx, lambda: d.decimate(LOG2DECIM, sd.FC_CEN, 16, x, out=y), [K_DECIMATE])
     out.append({"config": "configs[1]: %d streams x 2^%d samples, decimate16_cen (EO1), FEC off" % (S, n.bit_length() - 1),
                 "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
-                "roofline": roof(BYTES_DECIM * S * n, per[K_DECIMATE], decim_kernel_name())})
+                "roofline": roof(BYTES_DECIM * S * n, per[K_DECIMATE], decim_kernel_name(d.last_plan()))})
     del y
     # configs[2] literally: ONE stream (2^27 samples per step) through the fused Rx pipe
     n1 = 1 << 27
@@ -231,7 +239,7 @@ def extra_configs(ctx, dev, x, kind):
     wall, per = timed_steps(ctx, lambda: rx1.process_view(x1, tv_sec=1, tv_usec=0), [K_DECIMATE])
     out.append({"config": "configs[2] as one stream: 2^27 samples per step, decimate16_cen + framing + CM256 128+32",
                 "ms_per_step": round(wall, 4), "value": round(n1 / wall / 1e3, 1), "unit": "Msamples/s (input)",
-                "roofline": roof(BYTES_DECIM * n1, per[K_DECIMATE], decim_kernel_name())})
+                "roofline": roof(BYTES_DECIM * n1, per[K_DECIMATE], decim_kernel_name(rx1.last_plan()))})
     del x1, rx1
     # configs[3]: Tx pipe, 128+32 frames with 24 of the 160 blocks lost, a DIFFERENT random pattern in every frame,
     # frames resident on the device (block indices read from the headers by the planning kernel), interpolate by 16
@@ -255,17 +263,63 @@ def extra_configs(ctx, dev, x, kind):
     return out
 
 
+def verify_step(ctx, x, ids, kind):
+    """Behind the timed region: the SAME call on fresh handles (streams restart from the constructor state), whole output
+    digests.  With the default `hash` input and bench.py's own geometry the expected digests are the committed ones made
+    from the compiled reference decimator + the framer / encoder restatement (tests/golden/headline_golden.json); otherwise
+    the frames must equal those of the VALU kernel path.  -> dict for the `verified` key."""
+    import hashlib
+
+    import sdrdaemon_amd as sd
+
+    S, n = x.shape[0], x.shape[1]
+
+    def frames_digests(path):
+        ctx.set_option("decim_path", path)
+        try:
+            rx = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                           center_frequency_khz=435000, sample_rate=625000)
+            fr = rx.process_view(x, tv_sec=1, tv_usec=0).torch()
+            ctx.synchronize()
+            return [hashlib.sha256(fr[s].contiguous().cpu().numpy().tobytes()).hexdigest() for s in range(S)], rx.last_plan()["path"]
+        finally:
+            ctx.set_option("decim_path", "auto")
+
+    got, path = frames_digests("auto")
+    gold = None
+    if kind == "hash":
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "headline_golden.json")) as f:
+                H = json.load(f)
+            for name in ("bank8", "one27", "bank64"):
+                b = H[name]
+                if (1 << b["log2n"]) == n and all((1000 + sid) in b["seeds"] for sid in ids) and name != "one27":
+                    gold = [b["frames_sha256"][b["seeds"].index(1000 + sid)] for sid in ids]
+        except Exception:
+            gold = None
+    if gold is not None:
+        return {"ok": got == gold, "against": "tests/golden/headline_golden.json (compiled reference decimate16_cen + framer / CM256 restatement)",
+                "streams": S, "kernel_path": path, "what": "sha256 of every stream's whole frame stream of one step"}
+    exp, _ = frames_digests("valu")
+    return {"ok": got == exp, "against": "the VALU kernel path of this library on the same input (no committed digest for this geometry)",
+            "streams": S, "kernel_path": path, "what": "sha256 of every stream's whole frame stream of one step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2-samples", type=int, default=25, help="samples per stream per step (default 2^25)")
-    ap.add_argument("--streams", type=int, default=0,
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("SDRHIP_BENCH_STREAMS", "0")),
                     help="total streams of the job, sharded s -> rank s mod G (strong scaling, e.g. 64 = BASELINE configs[4]); "
-                         "default 0 = 8 streams per GPU (weak scaling)")
+                         "default 0 = 8 streams per GPU (weak scaling); the environment variable SDRHIP_BENCH_STREAMS sets the "
+                         "default for a driver that cannot add flags")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra single-GPU configurations of the `configs` key")
-    ap.add_argument("--input", choices=["noise", "testsource"], default="noise")
+    ap.add_argument("--input", choices=["hash", "noise", "testsource"], default="hash",
+                    help="hash: counter-based full-scale uniform noise (tests/signals.py) -- the input of the committed reference digests, "
+                         "so the run can verify its own output; noise: torch.randint; testsource: the library's GPU TestSource bank")
+    ap.add_argument("--no-verify", action="store_true", help="skip the output check behind the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--preroll-seconds", type=float, default=0.25,
                     help="untimed run-in of the same step before the W warm-up steps (the GPU's clocks ramp over the first "
@@ -315,6 +369,9 @@ def main():
         ids_by_rank = [None] * world
         dist.all_gather_object(ids_by_rank, ids)
     x = make_input(ctx, dev, n, [1000 + sid for sid in ids], args.input)
+    if rank == 0:
+        print("bench: %d rank(s), layout %s" % (world, ("strong: %d streams in total, stream s on rank s mod %d (SURVEY 8e)" % (args.streams, world))
+                                                if args.streams else "weak: %d streams per rank, stream id = rank * %d + s" % (S, S)), file=sys.stderr)
     rx = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
                    center_frequency_khz=435000, sample_rate=625000)
 
@@ -348,6 +405,9 @@ def main():
     dec_ms, dec_n = ctx.kernel_timing_read(K_DECIMATE)
     fec_ms, fec_n = ctx.kernel_timing_read(K_FEC_ENCODE)
     ctx.kernel_timing(False)
+    plan = rx.last_plan()
+    kname = decim_kernel_name(plan)
+    verified = None if args.no_verify else verify_step(ctx, x, ids, args.input)
     # the only collectives of the job: MAX of the elapsed time, SUM of the samples (8 bytes each, reporting only)
     elapsed, total_samples = sharding.aggregate(elapsed, float(S) * n * args.steps, dist,
                                                 dev if args.backend == "nccl" else torch.device("cpu"))
@@ -364,7 +424,8 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.streams else "weak",
             "vs_baseline": None, "dtype": "int32",
             "data": "synthetic: %s, %s, HBM-resident before the timed region" %
-                    ("uniform random full-scale int16 IQ" if args.input == "noise" else "GPU TestSource bank: 10 Msps CW, -20 dB, +100 kHz + 1 kHz x stream id",
+                    ("uniform random full-scale int16 IQ (counter-based hash, tests/signals.py)" if args.input == "hash" else
+                     "uniform random full-scale int16 IQ (torch.randint)" if args.input == "noise" else "GPU TestSource bank: 10 Msps CW, -20 dB, +100 kHz + 1 kHz x stream id",
                      ("%d streams in total, stream s on rank s mod %d" % (args.streams, world)) if args.streams else
                      ("%d streams/GPU (stream id = rank*%d + s)" % (S, S))),
             "config": {"workload": "configs[2] x %s: 10 Msps-shaped int16 IQ, decimate16_cen (EO1) + UDPSinkFEC framing + "
@@ -376,13 +437,15 @@ def main():
                        "parallelism": "stream-sharded x%d, no data-path collective" % world,
                        "stream_ids_by_rank": ids_by_rank if world * S <= 64 else "rank r: %s" % ("r, r+G, ..." if args.streams else "8r .. 8r+7")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(per_launch_samples),
-                         "kernel": decim_kernel_name(), "launches": dec_n, "avg_launch_ms": round(avg_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(per_launch_samples, kname),
+                         "traffic_source": "profiles/traffic.json (PMC passes of tools/prof.sh on this command, committed; not measured by this run)",
+                         "kernel": kname, "launches": dec_n, "avg_launch_ms": round(avg_ms, 4), "plan": plan,
                          "algorithmic_bytes_per_launch": BYTES_DECIM * per_launch_samples,
                          "pipe_gbps_config3": round(BYTES_CONFIG3 * value * 1e6 / 1e9 / world, 1),
                          "fec_encode_avg_launch_ms": round(fec_ms / max(fec_n, 1), 4), "fec_encode_launches": fec_n},
         }
-        lane_ops = pmc_valu_lane_ops(per_launch_samples)
+        res["verified"] = verified
+        lane_ops = pmc_valu_lane_ops(per_launch_samples, kname)
         if lane_ops and dec_n:
             # secondary figure of SURVEY.md 8(d): integer VALU issue, every op counted at the 16-lane / clk rate
             tl = lane_ops / (avg_ms * 1e-3) / 1e12

@@ -9,7 +9,9 @@
  * SDRHIP_E* code; sdrhip_last_error() gives the message of the calling thread's last
  * failure.
  *
- * Threading: a handle is single-threaded; different handles may be used concurrently.
+ * Threading: every entry point takes its context's (recursive) lock, so calls on the handles
+ * of one context serialise and may come from any thread; handles of different contexts run
+ * concurrently (objects that live on different threads in the reference own a context each).
  * Memory: every data pointer is either host memory (SDRHIP_MEM_HOST: the library
  * stages it through pinned buffers and copies back, synchronously) or device memory on
  * the context's GPU (SDRHIP_MEM_DEVICE: 16-byte aligned, work is enqueued on the
@@ -67,6 +69,11 @@ int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out);
  * handle to be destroyed frees it. */
 void sdrhip_ctx_destroy(sdrhip_ctx *ctx);
 int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
+/* Kernel-path knobs for tests and tools (production code never needs them).  The defaults are read from the environment
+ * ONCE, when the context is created (SDRHIP_DECIM_PATH, SDRHIP_MFMA_SPAN, SDRHIP_MFMA_MIN, SDRHIP_INTERP_PATH,
+ * SDRHIP_INTERP_SPAN, SDRHIP_RX_FUSED); keys: "decim_path" = auto | valu | mfma, "mfma_span" / "mfma_min" / "interp_span" =
+ * decimal sample counts, "interp_path" = valu | mfma, "rx_fused" = 0 | 1.  Every setting computes the same bytes. */
+int sdrhip_ctx_set_option(sdrhip_ctx *ctx, const char *key, const char *value);
 /* Average duration in milliseconds of the kernels launched between timing_begin and
  * timing_end on the context's stream, measured with hipEvents on that stream (what
  * bench.py's roofline object reports). */
@@ -90,6 +97,15 @@ typedef struct sdrhip_decimators sdrhip_decimators;
 int sdrhip_decimators_create(sdrhip_ctx *ctx, int nstreams, int hb_variant, sdrhip_decimators **out);
 void sdrhip_decimators_destroy(sdrhip_decimators *d);
 int sdrhip_decimators_reset(sdrhip_decimators *d); /* back to the constructor's zero state */
+/* What the bank's last cascade launch was (diagnostics: bench.py labels its roofline kernel with it, the parity tests
+ * assert that they ran the benchmarked geometry).  path: 0 = no cascade launch yet, 1 = VALU kernel (nseg segments per
+ * stream), 2 = matrix-core kernel (per stream: VALU head [0, head), wps waves x 8 spans of `span` samples, VALU tail from
+ * tail_start in npieces - 1 pieces). */
+typedef struct sdrhip_decim_plan {
+    int path, wps, npieces, nseg;
+    size_t span, head, tail_start;
+} sdrhip_decim_plan;
+int sdrhip_decimators_last_plan(const sdrhip_decimators *d, sdrhip_decim_plan *out);
 
 /* One Decimators::decimate<2^log2decim>_{inf,sup,cen}(sampleSize, in, out) call
  * (Decimators.h:35-53; dispatch of Downsampler::process, Downsampler.cpp:74-162) on each
@@ -206,13 +222,19 @@ int sdrhip_rx_reconfigure(sdrhip_rx *rx, const sdrhip_rx_config *cfg);
 /* Feeds n_in device-rate samples per stream.  Completed frames of stream s are written to
  * frames_out + s*frame_stride_bytes as (128 + nb_fec) super blocks of 512 bytes each,
  * frame after frame; *n_frames (per stream, identical for all streams) is the number of
- * frames completed by this call.  tv_sec/tv_usec stamp the meta block of frames STARTED by
- * this call (the reference calls gettimeofday there, UDPSinkFEC.cpp:91).  frames_out must
- * hold sdrhip_rx_max_frames(rx, n_in) frames per stream. */
+ * frames completed by this call.  tv_sec/tv_usec = the time of the call's FIRST sample; the
+ * meta block of every frame STARTED by this call carries that time advanced by the sample
+ * clock to the frame's first sample: + floor(p * 10^6 / sample_rate) microseconds for a frame
+ * that starts p decimated samples into the call (sample_rate = the configured rate of the
+ * frame stream; 0 = no advance), and the CRC-32 over it (the reference calls gettimeofday
+ * when it opens a frame, UDPSinkFEC.cpp:90-115; a batched call opens many at once).
+ * frames_out must hold sdrhip_rx_max_frames(rx, n_in) frames per stream. */
 int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in, size_t in_stride, uint32_t tv_sec,
                       uint32_t tv_usec, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames,
                       int mem);
 size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in);
+/* the decimator launch of the last sdrhip_rx_process call (see sdrhip_decimators_last_plan) */
+int sdrhip_rx_last_plan(const sdrhip_rx *rx, sdrhip_decim_plan *out);
 /* Zero-copy alternative for device-side consumers (what transmitUDP does when it sends straight
  * from m_txBlocks, UDPSinkFEC.cpp:259-282): call sdrhip_rx_process with frames_out = NULL and
  * mem = SDRHIP_MEM_DEVICE, then read the n_frames finished frames of stream s at

@@ -323,6 +323,12 @@ size_t orc_framer_write(orc_framer *f, const int16_t *iq, size_t n, uint8_t *fra
             m.nb_fec_blocks = f->nb_fec_blocks;
             m.tv_sec = f->tv_sec;
             m.tv_usec = f->tv_usec;
+            if (f->stamp_from_samples && f->sample_rate) {
+                uint64_t dus = (uint64_t)pos * 1000000ull / f->sample_rate;
+                m.tv_usec += (uint32_t)(dus % 1000000ull);
+                m.tv_sec += (uint32_t)(dus / 1000000ull);
+                if (m.tv_usec >= 1000000u) { m.tv_usec -= 1000000u; m.tv_sec += 1; }
+            }
             m.crc32 = orc_crc32(&m, 20);
             memset(f->cur, 0, ORC_UDPSIZE);
             f->cur[0] = (uint8_t)(f->frame_count & 0xFF);

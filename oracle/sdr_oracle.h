@@ -103,6 +103,11 @@ typedef struct {
     uint32_t center_frequency_khz, sample_rate;
     uint8_t sample_bytes, sample_bits, nb_fec_blocks;
     uint32_t tv_sec, tv_usec;
+    /* 0: every frame a write() opens carries (tv_sec, tv_usec) as it is (the test plays gettimeofday, UDPSinkFEC.cpp:91);
+     * 1: (tv_sec, tv_usec) is the time of the write() call's FIRST sample and a frame opened p samples into the call is
+     * stamped floor(p * 10^6 / sample_rate) microseconds later (the rule of the batched product, where one call opens many
+     * frames: sdrhip_internal.h frame_meta_words) */
+    int stamp_from_samples;
 } orc_framer;
 void orc_framer_init(orc_framer *f);
 /* Feeds n samples; every completed frame is appended to frames_out as

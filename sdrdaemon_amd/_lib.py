@@ -23,7 +23,7 @@ HB_EO1, HB_DB = 0, 1
 UDPSIZE, NB_ORIGINAL, BLOCK_BYTES, SAMPLES_PER_BLOCK, SAMPLES_PER_FRAME = 512, 128, 508, 127, 16129
 
 EXPORTS = [
-    "sdrhip_last_error", "sdrhip_device_count", "sdrhip_ctx_create", "sdrhip_ctx_destroy", "sdrhip_ctx_synchronize",
+    "sdrhip_last_error", "sdrhip_device_count", "sdrhip_ctx_create", "sdrhip_ctx_destroy", "sdrhip_ctx_synchronize", "sdrhip_ctx_set_option", "sdrhip_decimators_last_plan", "sdrhip_rx_last_plan",
     "sdrhip_ctx_timing_begin", "sdrhip_ctx_timing_end", "sdrhip_ctx_kernel_timing", "sdrhip_ctx_kernel_timing_read", "sdrhip_decimators_create", "sdrhip_decimators_destroy",
     "sdrhip_decimators_reset", "sdrhip_decimate", "sdrhip_interpolators_create", "sdrhip_interpolators_destroy",
     "sdrhip_interpolators_reset", "sdrhip_interpolate", "sdrhip_cm256_encode", "sdrhip_cm256_decode",
@@ -47,6 +47,11 @@ class CM256Block(C.Structure):
     _fields_ = [("Block", C.c_void_p), ("Index", C.c_ubyte)]
 
 
+class DecimPlan(C.Structure):
+    _fields_ = [("path", C.c_int), ("wps", C.c_int), ("npieces", C.c_int), ("nseg", C.c_int),
+                ("span", C.c_size_t), ("head", C.c_size_t), ("tail_start", C.c_size_t)]
+
+
 class RxConfig(C.Structure):
     _fields_ = [("log2decim", C.c_int), ("fcpos", C.c_int), ("hb_variant", C.c_int), ("sample_bits", C.c_uint),
                 ("nb_fec", C.c_int), ("center_frequency_khz", C.c_uint32), ("sample_rate", C.c_uint32)]
@@ -64,6 +69,9 @@ def load():
     lib.sdrhip_ctx_destroy.argtypes = [vp]
     lib.sdrhip_ctx_destroy.restype = None
     lib.sdrhip_ctx_synchronize.argtypes = [vp]
+    lib.sdrhip_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.sdrhip_decimators_last_plan.argtypes = [vp, C.POINTER(DecimPlan)]
+    lib.sdrhip_rx_last_plan.argtypes = [vp, C.POINTER(DecimPlan)]
     lib.sdrhip_ctx_timing_begin.argtypes = [vp]
     lib.sdrhip_ctx_timing_end.argtypes = [vp, C.POINTER(C.c_float)]
     lib.sdrhip_ctx_kernel_timing.argtypes = [vp, i]

@@ -324,11 +324,13 @@ __device__ __forceinline__ void decim_piece(const DecimArgs &a, int *lds, int st
     // fused Rx pipe: meta block + super block headers of the frames this call starts, one frame per
     // workgroup (frame i of the stream by segment i mod nseg); nothing else writes those dwords
     if (a.frame_mode && tid < 128) {
-        unsigned mw = 0u; // dword tid of block 0 behind the header: the 24-byte MetaDataFEC, then zeros
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (tid == k + 1) mw = a.meta_w[k];
         for (int fi = meta_id; fi < a.meta_count; fi += meta_n) {
+            unsigned w[6];
+            frame_meta_words(a.meta_w, a.meta_idx0, a.meta_rate, fi, w); // per-frame time stamp + CRC (wave-uniform)
+            unsigned mw = 0u; // dword tid of block 0 behind the header: the 24-byte MetaDataFEC, then zeros
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (tid == k + 1) mw = w[k];
             unsigned *fr = oc.out + (size_t)(a.meta_first + fi) * a.frame_blocks * 128u;
             const unsigned fidx = (a.meta_frame_count0 + (unsigned)fi) & 0xffffu;
             fr[tid] = tid == 0 ? fidx : mw; // block 0: 512 bytes = 128 dwords

@@ -414,8 +414,12 @@ template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream
 
 } // namespace
 
-bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, size_t span_override, DecimArgs *a)
+bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, size_t span_override, int n_cu, DecimArgs *a)
 {
+    // one wave per SIMD on all but one CU of every XCD (MI355X: 8 XCDs x 32 CUs -> 31 workgroups per XCD, 992 waves)
+    const int nxcd = n_cu >= 64 && n_cu % 8 == 0 ? 8 : 1;
+    const size_t waves1 = (size_t)4 * (size_t)(n_cu > nxcd ? n_cu - nxcd : n_cu);
+    const size_t waves3 = 3 * waves1 - waves1 / 13; // a round of three waves per SIMD with some slack (2900 on MI355X)
     if (fcpos != 2 || log2decim < 2 || log2decim > 6) return false; // (decimate2_cen: the VALU kernel is HBM-bound, 63 % against 59 %)
     const size_t W = (size_t)64 << log2decim;     // one period of the schedule = the warm-up
     const size_t head = W > 2048 ? W : 2048;      // VALU head piece: whole passes, >= the warm-up of the first span
@@ -430,8 +434,8 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
             // short cascades (decimate4 / 8): TWO waves per SIMD, 62 workgroups per XCD (1984 waves), the spans sized from
             // the wave count like below (tools/sweep_span.sh: 0.238 / 0.262 ms per 2^28 samples against 0.248 / 0.271 with
             // one round of three waves per SIMD, 0.250 / 0.318 with one wave per SIMD); three per SIMD for bigger banks
-            S = (total / (2900 * 8) + W - 1) / W * W;
-            const size_t wps2 = 1984 / (size_t)nstreams;
+            S = (total / (waves3 * 8) + W - 1) / W * W;
+            const size_t wps2 = 2 * waves1 / (size_t)nstreams;
             if (wps2 >= 1) {
                 size_t S2 = n / (8 * wps2) / W * W;
                 if (S2 == 0 || n / (8 * S2) > wps2) S2 += W; // (rounding down must not add a wave)
@@ -446,7 +450,7 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
             // from the wave count so that the VALU tail stays short.  Banks too big for that (spans beyond the limit of
             // the planner): spans of 32 Ki samples, the waves are dealt dynamically over many rounds.
             const size_t SL = 32768 > 8 * W ? 32768 : 8 * W;
-            const size_t wps1 = 992 / (size_t)nstreams;
+            const size_t wps1 = waves1 / (size_t)nstreams;
             S = SL;
             if (wps1 >= 1) {
                 size_t S1 = n / (8 * wps1) / W * W;

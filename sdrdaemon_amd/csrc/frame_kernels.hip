@@ -34,11 +34,13 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(FrameArgs a)
     // meta block + super block headers of the frames this call starts: frame fi by workgroup fi mod gridDim.x
     if (threadIdx.x < 128) {
         const unsigned t = threadIdx.x;
-        unsigned mw = 0u; // dword t of block 0 behind the header: the 24-byte MetaDataFEC, then zeros
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-            if (t == (unsigned)k + 1u) mw = a.meta_w[k];
         for (int fi = blockIdx.x; fi < a.meta_count; fi += gridDim.x) {
+            unsigned w[6];
+            frame_meta_words(a.meta_w, a.meta_idx0, a.meta_rate, fi, w); // per-frame time stamp + CRC (wave-uniform)
+            unsigned mw = 0u; // dword t of block 0 behind the header: the 24-byte MetaDataFEC, then zeros
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (t == (unsigned)k + 1u) mw = w[k];
             unsigned *fr = dst + (size_t)(a.meta_first + fi) * fdw;
             const unsigned fidx = (a.meta_frame_count0 + (unsigned)fi) & 0xffffu;
             fr[t] = t == 0 ? fidx : mw; // block 0: 512 bytes = 128 dwords

@@ -112,6 +112,16 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
     if (!c) return fail(SDRHIP_ENOMEM, "out of host memory");
     c->device = device;
     c->stream = static_cast<hipStream_t>(hip_stream);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+        // the environment is read here, once (getenv is not safe against a concurrent setenv): later changes go through
+        // sdrhip_ctx_set_option()
+        static const char *const keys[][2] = {{"SDRHIP_DECIM_PATH", "decim_path"}, {"SDRHIP_MFMA_SPAN", "mfma_span"}, {"SDRHIP_MFMA_MIN", "mfma_min"},
+                                              {"SDRHIP_INTERP_PATH", "interp_path"}, {"SDRHIP_INTERP_SPAN", "interp_span"}, {"SDRHIP_RX_FUSED", "rx_fused"}};
+        for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); ++i)
+            if (const char *v = getenv(keys[i][0])) (void)sdrhip_ctx_set_option(c, keys[i][1], v);
+    }
     std::vector<uint8_t> tab(256 * 32);
     gf_build_tables(tab.data());
     if (hipMalloc(reinterpret_cast<void **>(&c->gf_tab), tab.size()) != hipSuccess) { c->gf_tab = nullptr; ctx_free(c); return fail(SDRHIP_ENOMEM, "hipMalloc gf tables"); }
@@ -150,9 +160,34 @@ void ctx_release(sdrhip_ctx *c)
 // last handle to go frees it (destruction order is then irrelevant, e.g. under a garbage collector).
 extern "C" void sdrhip_ctx_destroy(sdrhip_ctx *c)
 {
-    if (!c || c->dying) return;
-    c->dying = true;
+    if (!c || c->dying.exchange(true)) return;
     if (c->refs.load() == 0) ctx_free(c);
+}
+
+// Kernel-path knobs (tests and tools; the defaults come from the environment at creation).  Unknown keys / values: EINVAL.
+extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char *value)
+{
+    if (!c || !key || !value) return fail(SDRHIP_EINVAL, "ctx_set_option: NULL argument");
+    sdrhip::CtxLock lock_(c);
+    const std::string k(key), v(value);
+    char *end = nullptr;
+    const unsigned long long num = strtoull(value, &end, 10);
+    const bool isnum = *value && end && !*end;
+    if (k == "decim_path") {
+        if (v == "auto") c->opt.decim_path = DECIM_PATH_AUTO;
+        else if (v == "valu") c->opt.decim_path = DECIM_PATH_VALU;
+        else if (v == "mfma") c->opt.decim_path = DECIM_PATH_MFMA;
+        else return fail(SDRHIP_EINVAL, "ctx_set_option: decim_path must be auto, valu or mfma");
+    } else if (k == "interp_path") {
+        if (v == "valu" || v == "auto") c->opt.interp_mfma = 0;
+        else if (v == "mfma") c->opt.interp_mfma = 1;
+        else return fail(SDRHIP_EINVAL, "ctx_set_option: interp_path must be valu or mfma");
+    } else if (k == "mfma_span" && isnum) c->opt.mfma_span = (size_t)num;
+    else if (k == "mfma_min" && isnum) c->opt.mfma_min = (size_t)num;
+    else if (k == "interp_span" && isnum) c->opt.interp_span = (size_t)num;
+    else if (k == "rx_fused" && isnum) c->opt.rx_fused = num ? 1 : 0;
+    else return fail(SDRHIP_EINVAL, "ctx_set_option: unknown key or malformed value: %s=%s", key, value);
+    return SDRHIP_OK;
 }
 
 static void sdrhip::ctx_free(sdrhip_ctx *c)
@@ -233,7 +268,17 @@ struct sdrhip_decimators {
     int32_t *state[2]; // double buffered [nstreams][DEC_STATE_WORDS]
     int cur;
     bool stage0_int16; // history of m_decimator2 fits int16 (it last saw raw samples or nothing)
+    sdrhip::DecimPlanInfo last; // what the last call launched
 };
+
+extern "C" int sdrhip_decimators_last_plan(const sdrhip_decimators *d, sdrhip_decim_plan *out)
+{
+    if (!d || !out) return fail(SDRHIP_EINVAL, "decimators_last_plan: NULL argument");
+    sdrhip::CtxLock lock_(d->ctx);
+    out->path = d->last.path; out->wps = d->last.wps; out->npieces = d->last.npieces; out->nseg = d->last.nseg;
+    out->span = d->last.span; out->head = d->last.head; out->tail_start = d->last.tail_start;
+    return SDRHIP_OK;
+}
 
 extern "C" int sdrhip_decimators_create(sdrhip_ctx *ctx, int nstreams, int hb_variant, sdrhip_decimators **out)
 {
@@ -280,27 +325,10 @@ extern "C" int sdrhip_decimators_reset(sdrhip_decimators *d)
 }
 
 namespace {
-enum { DECIM_PATH_AUTO = 0, DECIM_PATH_VALU = 1, DECIM_PATH_MFMA = 2 };
-struct DecimPathEnv {
-    int path;
-    size_t span, min_samples;
-};
-DecimPathEnv decim_path_env()
-{
-    DecimPathEnv e;
-    e.path = DECIM_PATH_AUTO; e.span = 0; e.min_samples = (size_t)1 << 22;
-    if (const char *p = getenv("SDRHIP_DECIM_PATH")) {
-        if (!strcmp(p, "valu")) e.path = DECIM_PATH_VALU;
-        else if (!strcmp(p, "mfma")) e.path = DECIM_PATH_MFMA;
-    }
-    if (const char *p = getenv("SDRHIP_MFMA_SPAN")) e.span = (size_t)strtoull(p, nullptr, 10);
-    if (const char *p = getenv("SDRHIP_MFMA_MIN")) e.min_samples = (size_t)strtoull(p, nullptr, 10);
-    return e;
-}
 // A launch of the matrix-core kernel lasts at least one warm-up + the shortest span, i.e. ~20 us at decimate16 and
 // twice as long per further stage, however small the call; below these sizes the VALU kernel is faster
 // (tools/bench_small.py): 2^22 samples over all streams up to decimate8, 2^23 for decimate16, 2^24, 2^25.
-size_t mfma_min_samples(const DecimPathEnv &e, int log2decim) { return e.min_samples << (log2decim > 3 ? log2decim - 3 : 0); }
+size_t mfma_min_samples(const CtxOptions &o, int log2decim) { return o.mfma_min << (log2decim > 3 ? log2decim - 3 : 0); }
 } // namespace
 
 namespace sdrhip {
@@ -348,16 +376,17 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     if (meta) {
         a.meta_first = meta->first; a.meta_count = meta->count; a.meta_frame_count0 = meta->frame_count0;
         memcpy(a.meta_w, meta->w, sizeof(a.meta_w));
+        a.meta_idx0 = meta->idx0; a.meta_rate = meta->rate;
     }
     plan_decimate((int)L, fcpos, a.n_used, d->nstreams, &a.nsub_per_seg, &a.nseg);
     const bool cen = (fcpos == SDRHIP_FC_CEN);
     const bool pack16 = cen && d->stage0_int16;
     // matrix-core cascade for the centred modes when the call is long enough to fill the chip;
     // SDRHIP_DECIM_PATH = valu | mfma | auto (default), SDRHIP_MFMA_SPAN = span length in samples (tests)
-    const DecimPathEnv env = decim_path_env(); // (read per call: tests switch paths inside one process)
+    const CtxOptions &env = c->opt;
     bool use_mfma = false;
-    if (!frame_mode && env.path != DECIM_PATH_VALU && (env.path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= mfma_min_samples(env, (int)L)))
-        use_mfma = plan_decimate_mfma((int)L, fcpos, a.n_used, d->nstreams, env.span, &a);
+    if (!frame_mode && env.decim_path != DECIM_PATH_VALU && (env.decim_path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= mfma_min_samples(env, (int)L)))
+        use_mfma = plan_decimate_mfma((int)L, fcpos, a.n_used, d->nstreams, env.mfma_span, c->n_cu, &a);
     a.mf_dump = c->decim_dump;
     hipError_t e;
     {
@@ -365,6 +394,9 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
         e = use_mfma ? launch_decimate_mfma((int)L, pack16, a, c->stream) : launch_decimate((int)L, fcpos, pack16, a, c->stream);
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "decimate launch: %s", hipGetErrorString(e));
+    d->last.path = use_mfma ? DECIM_PATH_MFMA : DECIM_PATH_VALU;
+    d->last.span = use_mfma ? a.mf_span : 0; d->last.head = use_mfma ? a.mf_head : 0; d->last.tail_start = use_mfma ? a.mf_tail_start : 0;
+    d->last.wps = use_mfma ? a.mf_wps : 0; d->last.npieces = use_mfma ? a.mf_npieces : 0; d->last.nseg = use_mfma ? 0 : a.nseg;
     d->cur ^= 1;
     // m_decimator2's 64-entry history now holds raw int16 samples (cen) or rotate-sums (inf/sup); a centred
     // call shorter than the history leaves older rotate-sums in it, which the packed-int16 first stage
@@ -379,11 +411,11 @@ namespace sdrhip {
 // a stream-order buffer and frames it with K2 instead of using the VALU kernel's fused frame epilogue.)
 bool decimate_mfma_applies(const sdrhip_decimators *d, int log2decim, int fcpos, size_t n_in)
 {
-    const DecimPathEnv env = decim_path_env();
+    const CtxOptions &env = d->ctx->opt;
     const size_t n_used = (n_in >> log2decim) << log2decim;
-    if (env.path == DECIM_PATH_VALU || (env.path != DECIM_PATH_MFMA && n_used * (size_t)d->nstreams < mfma_min_samples(env, log2decim))) return false;
+    if (env.decim_path == DECIM_PATH_VALU || (env.decim_path != DECIM_PATH_MFMA && n_used * (size_t)d->nstreams < mfma_min_samples(env, log2decim))) return false;
     DecimArgs tmp;
-    return plan_decimate_mfma(log2decim, fcpos, n_used, d->nstreams, env.span, &tmp);
+    return plan_decimate_mfma(log2decim, fcpos, n_used, d->nstreams, env.mfma_span, d->ctx->n_cu, &tmp);
 }
 } // namespace sdrhip
 

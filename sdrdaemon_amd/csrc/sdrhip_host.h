@@ -51,7 +51,9 @@ void ctx_release(sdrhip_ctx *c);
 struct RxMeta {
     int first, count;
     unsigned frame_count0;
-    unsigned w[6]; // MetaDataFEC, 24 bytes
+    unsigned w[6]; // MetaDataFEC, 24 bytes: w[3], w[4] = time stamp of the call's first sample; the kernels advance it per frame and add the CRC
+    uint64_t idx0; // call-relative decimated-sample index of the first started frame's first sample
+    unsigned rate; // sample rate the stamps advance with (Hz, 0 = none)
 };
 
 // sampleSize after decimateN (Decimators.cpp:43-44, 112-113 ...): grows by log2decim, capped at 16 bits
@@ -89,15 +91,38 @@ int fec_decode_device(sdrhip_ctx *ctx, const uint8_t *rx, size_t rx_frame_bytes,
 
 } // namespace sdrhip
 
+namespace sdrhip {
+enum { DECIM_PATH_AUTO = 0, DECIM_PATH_VALU = 1, DECIM_PATH_MFMA = 2 };
+// Kernel-path knobs of a context.  Read ONCE from the environment when the context is created (SDRHIP_DECIM_PATH =
+// valu | mfma | auto, SDRHIP_MFMA_SPAN, SDRHIP_MFMA_MIN, SDRHIP_INTERP_PATH = valu | mfma, SDRHIP_INTERP_SPAN); afterwards
+// only sdrhip_ctx_set_option() changes them (tests, tools), under the context's lock.
+struct CtxOptions {
+    int decim_path = DECIM_PATH_AUTO;
+    size_t mfma_span = 0;                  // forced span length of the matrix-core decimator (0 = planner's choice)
+    size_t mfma_min = (size_t)1 << 22;     // smallest call (samples over all streams, decimate4 / 8) the matrix cores take in auto mode
+    int interp_mfma = 0;
+    size_t interp_span = 0;
+    int rx_fused = 1;                      // Rx pipe: encoder in the decimator's launch (0 = separate launches)
+};
+// what the last decimate / rx call of a bank actually launched (sdrhip_decimators_last_plan)
+struct DecimPlanInfo {
+    int path = 0;       // 0 none yet, DECIM_PATH_VALU, DECIM_PATH_MFMA
+    size_t span = 0, head = 0, tail_start = 0;
+    int wps = 0, npieces = 0, nseg = 0;
+};
+} // namespace sdrhip
+
 struct sdrhip_ctx {
     // Every public entry point that works on this context (directly or through one of its handles) holds this lock
     // for its duration: the staging buffers, the decode-plan cache and the timing log are per context.  Calls on
     // one context therefore serialise; threads that want to overlap use one context each.
     std::recursive_mutex mtx;
     int device = 0;
+    int n_cu = 256;                          // hipDeviceProp_t::multiProcessorCount (the planners size their grids from it)
+    sdrhip::CtxOptions opt;
     hipStream_t stream = nullptr;
     std::atomic<int> refs{0}; // handles created on this context (they keep it alive)
-    bool dying = false; // sdrhip_ctx_destroy was called while handles were still alive
+    std::atomic<bool> dying{false}; // sdrhip_ctx_destroy was called while handles were still alive
     sdrhip::DevBuf in, out, aux, aux3;       // staging for SDRHIP_MEM_HOST calls and FEC work areas
     uint8_t *gf_tab = nullptr;               // 256 x 32 B multiplier tables (device)
     uint8_t *enc_matrix = nullptr;           // 128 x 128 encode matrix, rows 128..255 (device)

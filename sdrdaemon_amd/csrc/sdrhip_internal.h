@@ -46,6 +46,8 @@ struct DecimArgs {
     int meta_first, meta_count;
     unsigned meta_frame_count0;
     unsigned meta_w[6];
+    uint64_t meta_idx0;  // decimated-sample index (counted from the call's first sample) at which frame meta_first starts
+    unsigned meta_rate;  // sample rate of the frame stream in Hz (0: every frame carries the call's time stamp), see frame_meta_words()
     // matrix-core launch (decim_mfma.hip): per stream the VALU code runs the head [0, mf_head) and the tail
     // [mf_tail_start, n_used) in pieces of mf_tail_seg samples (mf_npieces = 1 + tail pieces workgroups), the
     // matrix-core waves run mf_wps groups of 8 spans of mf_span raw samples from mf_head on
@@ -54,6 +56,36 @@ struct DecimArgs {
     unsigned *mf_dump;   // >= 1 KiB of device memory that swallows the stores of the warm-up period
 };
 
+// MetaDataFEC of the fi-th frame a call starts (UDPSinkFEC.cpp:90-115: the reference takes gettimeofday() when it opens a
+// frame and CRCs the first 20 bytes).  A batched call opens all its frames "at once", so the stamp of a frame is the
+// call's stamp (base[3] = tv_sec, base[4] = tv_usec: the time of the call's first sample) advanced by the sample clock:
+// frame fi starts idx0 + fi * 16129 samples into the call, i.e. floor(idx * 10^6 / rate) microseconds later.  CRC-32
+// (boost::crc_32_type = reflected 0xEDB88320) bit-serially over the five little-endian words: ~500 scalar instructions
+// per frame, wave-uniform.  (The test-side framer applies the same rule: DESIGN.md K2.)
+#ifdef __HIPCC__
+__device__ __forceinline__ void frame_meta_words(const unsigned (&base)[6], uint64_t idx0, unsigned rate, int fi, unsigned (&w)[6])
+{
+    unsigned sec = base[3], usec = base[4];
+    if (rate) {
+        const uint64_t idx = idx0 + (uint64_t)fi * 16129u;
+        const uint64_t dus = idx * 1000000ull / rate;
+        const uint64_t ds = dus / 1000000ull;
+        usec += (unsigned)(dus - ds * 1000000ull);
+        sec += (unsigned)ds;
+        if (usec >= 1000000u) { usec -= 1000000u; sec += 1u; }
+    }
+    w[0] = base[0]; w[1] = base[1]; w[2] = base[2]; w[3] = sec; w[4] = usec;
+    unsigned crc = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (int k = 0; k < 5; ++k) {
+        crc ^= w[k];
+#pragma unroll 8
+        for (int b = 0; b < 32; ++b) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+    }
+    w[5] = ~crc;
+}
+#endif
+
 // returns hipSuccess or the launch error
 hipError_t launch_decimate(int log2decim, int fcpos, bool pack16, const DecimArgs &a, hipStream_t stream);
 // picks nsub_per_seg / nseg for a call (host helper living next to the kernel's geometry)
@@ -61,7 +93,7 @@ void plan_decimate(int log2decim, int fcpos, size_t n_used, int nstreams, int *n
 
 // matrix-core variant of the centred cascades: fills the mf_* fields, false when the call is too short (or the
 // mode unsupported); span_override != 0 forces the span length (tests)
-bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, size_t span_override, DecimArgs *a);
+bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, size_t span_override, int n_cu, DecimArgs *a);
 hipError_t launch_decimate_mfma(int log2decim, bool pack16, const DecimArgs &a, hipStream_t stream);
 
 // filter-less paths: log2decim 0 (decimate1) and inf/sup 2, 4 (Decimators.cpp:22-91,127-170)
@@ -90,6 +122,8 @@ struct FrameArgs {
     int meta_first, meta_count; // as DecimArgs::meta_*
     unsigned meta_frame_count0;
     unsigned meta_w[6];
+    uint64_t meta_idx0;
+    unsigned meta_rate;
 };
 hipError_t launch_frame_pack(const FrameArgs &a, int nstreams, hipStream_t stream);
 

@@ -78,13 +78,7 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
     // SDRHIP_INTERP_PATH=mfma selects the matrix-core cascade (interp_mfma.hip, DESIGN.md "K5m": bit-exact but slower
     // than the VALU kernel, kept as a measured experiment); SDRHIP_INTERP_SPAN = span length in inputs (tests)
     bool use_mfma = false;
-    if (const char *pe = getenv("SDRHIP_INTERP_PATH")) {
-        if (!strcmp(pe, "mfma")) {
-            size_t span = 0;
-            if (const char *v = getenv("SDRHIP_INTERP_SPAN")) span = (size_t)strtoull(v, nullptr, 10);
-            use_mfma = plan_interpolate_mfma(log2interp, n_in, p->nstreams, span, &a);
-        }
-    }
+    if (c->opt.interp_mfma) use_mfma = plan_interpolate_mfma(log2interp, n_in, p->nstreams, c->opt.interp_span, &a);
     if (!use_mfma) plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
     a.mf_dump = c->decim_dump;
     hipError_t e;
@@ -230,6 +224,12 @@ extern "C" int sdrhip_rx_frames_view(const sdrhip_rx *rx, const uint8_t **base, 
     return SDRHIP_OK;
 }
 
+extern "C" int sdrhip_rx_last_plan(const sdrhip_rx *rx, sdrhip_decim_plan *out)
+{
+    if (!rx) return fail(SDRHIP_EINVAL, "rx is NULL");
+    return sdrhip_decimators_last_plan(rx->dec, out);
+}
+
 extern "C" size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in)
 {
     if (!rx) return 0;
@@ -313,17 +313,15 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         m[8] = (uint8_t)((ssd - 1) / 8 + 1); // setSampleBytes((sampleSize - 1) / 8 + 1), sdrdaemonrx.cpp:643
         m[9] = (uint8_t)ssd;                 // setSampleBits(sampleSize), :642
         m[10] = SDRHIP_NB_ORIGINAL; m[11] = (uint8_t)R;
-        memcpy(m + 12, &tv_sec, 4); memcpy(m + 16, &tv_usec, 4);
-        // boost::crc_32_type over the first 20 bytes (UDPSinkFEC.cpp:106-109)
-        uint32_t crc = 0xFFFFFFFFu;
-        for (int i = 0; i < 20; ++i) {
-            crc ^= m[i];
-            for (int k = 0; k < 8; ++k) crc = (crc & 1) ? 0xEDB88320u ^ (crc >> 1) : crc >> 1;
-        }
-        crc ^= 0xFFFFFFFFu;
-        memcpy(m + 20, &crc, 4);
+        // tv_sec / tv_usec = the stamp of the call's first sample; a frame's own stamp (the reference calls gettimeofday when it
+        // opens the frame, UDPSinkFEC.cpp:90-104) is that plus its first sample's offset on the sample clock, and the
+        // boost::crc_32_type over the first 20 bytes (:106-109) follows from it: both per frame on the device (frame_meta_words)
+        const uint32_t crc = 0;
+        memcpy(m + 12, &tv_sec, 4); memcpy(m + 16, &tv_usec, 4); memcpy(m + 20, &crc, 4);
         meta.first = first_new; meta.count = started; meta.frame_count0 = (unsigned)rx->frame_count + first_new;
         memcpy(meta.w, m, 24);
+        meta.idx0 = first_new ? (uint64_t)SDRHIP_SAMPLES_PER_FRAME - rx->pending_samples : 0;
+        meta.rate = sr;
     }
 
     size_t n_out = 0;
@@ -357,6 +355,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         fa.n = n_dec; fa.frame_sample_base = rx->pending_samples; fa.frame_blocks = FB;
         fa.meta_first = meta.first; fa.meta_count = meta.count; fa.meta_frame_count0 = meta.frame_count0;
         memcpy(fa.meta_w, meta.w, sizeof(fa.meta_w));
+        fa.meta_idx0 = meta.idx0; fa.meta_rate = meta.rate;
         hipError_t e = launch_frame_pack(fa, S, c->stream);
         if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "frame pack launch: %s", hipGetErrorString(e));
     } else {

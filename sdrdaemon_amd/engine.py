@@ -54,6 +54,11 @@ class Context:
     def synchronize(self):
         check(self.lib.sdrhip_ctx_synchronize(self.h))
 
+    def set_option(self, key, value):
+        """kernel-path knobs for tests and tools (sdrhip_ctx_set_option): decim_path, mfma_span, mfma_min, interp_path,
+        interp_span, rx_fused; the defaults were read from the SDRHIP_* environment when the context was created"""
+        check(self.lib.sdrhip_ctx_set_option(self.h, str(key).encode(), str(value).encode()))
+
     def timing_begin(self):
         check(self.lib.sdrhip_ctx_timing_begin(self.h))
 
@@ -122,6 +127,13 @@ def _alloc_like(x, shape, dtype_np=np.int16):
     return np.empty(shape, dtype=dtype_np)
 
 
+def _plan_dict(fn, h):
+    p = _lib.DecimPlan()
+    check(fn(h, C.byref(p)))
+    return {"path": {0: None, 1: "valu", 2: "mfma"}[p.path], "span": p.span, "wps": p.wps, "npieces": p.npieces, "nseg": p.nseg,
+            "head": p.head, "tail_start": p.tail_start}
+
+
 class Decimators:
     """Bank of reference `Decimators` objects (Decimators.h:32-71)."""
 
@@ -154,6 +166,10 @@ class Decimators:
                                            _stride_samples(out) if S > 1 else n_res, C.byref(n_out),
                                            MEM_DEVICE if is_t else MEM_HOST))
         return (out[0] if squeeze else out), ss.value
+
+    def last_plan(self):
+        """what the last cascade launch was (sdrhip_decimators_last_plan): dict with path ('valu' / 'mfma' / None), span, wps, ..."""
+        return _plan_dict(self.ctx.lib.sdrhip_decimators_last_plan, self.h)
 
     def close(self):
         if self.h:
@@ -433,6 +449,10 @@ class RxPipe:
     def error(self):
         e, self.m_error = self.m_error, ""
         return e
+
+    def last_plan(self):
+        """the decimator launch of the last process() call (sdrhip_rx_last_plan)"""
+        return _plan_dict(self.ctx.lib.sdrhip_rx_last_plan, self.h)
 
     def reconfigure(self, **kw):
         """Live change between two process() calls (sdrhip_rx_reconfigure): any of log2decim, fcpos,

@@ -85,6 +85,76 @@ def main():
         json.dump({"cases": index, "big": big}, f, indent=0)
     print("cases:", len(index), "arrays:", len(arrays))
     fec_golden()
+    long_golden()
+    headline_golden()
+
+
+def long_golden():
+    """Centred cascades on inputs long enough for the matrix-core kernel to engage at EVERY ratio (decimate64 needs 4096 + 8
+    spans of 4096 samples): 65536 samples, one call and a ragged two-call split, both flavours -> dsp_golden_long.npz."""
+    arrays, index = {}, []
+    inputs = {"noise": signals.noise(65536, 77), "mixed": signals.mixed(65536, 78), "alternating": signals.alternating(65536)}
+    for k, v in inputs.items():
+        arrays["in_" + k] = v
+    for flav in ("eo1", "db"):
+        ref = Reference(flav)
+        for sig, x in inputs.items():
+            for log2 in range(2, 7):
+                for chunks in ([65536], [40000 + 16, 25536 - 16]):
+                    d = ref.decimators()
+                    outs, pos = [], 0
+                    for c in chunks:
+                        o, ss_out = d.decimate(log2, 2, 16, x[pos:pos + c])
+                        outs.append(o)
+                        pos += c
+                    key = "declong_%s_%s_L%d_c%d" % (flav, sig, log2, len(chunks))
+                    arrays[key] = np.concatenate(outs)
+                    index.append({"key": key, "kind": "decimate", "flavour": flav, "bias": ref.bias, "input": sig, "sample_size": 16,
+                                  "sample_size_out": ss_out, "fcpos": 2, "log2": log2, "chunks": chunks})
+    np.savez_compressed(os.path.join(HERE, "dsp_golden_long.npz"), **arrays)
+    with open(os.path.join(HERE, "dsp_golden_long.json"), "w") as f:
+        json.dump({"cases": index}, f, indent=0)
+    print("long cases:", len(index))
+
+
+HEADLINE_META = {"tv_sec": 1, "tv_usec": 0, "center_frequency_khz": 435000, "sample_rate": 625000, "nb_fec": 32}
+
+
+def _headline_stream(ref, orc, n, seed):
+    """one stream of the benchmark: signals.hash_noise(n, seed) -> the REFERENCE's decimate16_cen (EO1 build, one call)
+    -> UDPSinkFEC framing + CM256 128+32 (the oracle's framer with the product's time-stamp rule, and its encoder).
+    -> (sha256 of the decimated stream, sha256 of the finished frames [f][160][512], number of frames)"""
+    x = signals.hash_noise(n, seed)
+    y, ss = ref.decimators().decimate(4, 2, 16, x)
+    assert ss == 16 and y.shape[0] == n >> 4
+    m = HEADLINE_META
+    fr = orc.framer(nb_fec_blocks=m["nb_fec"], tv_sec=m["tv_sec"], tv_usec=m["tv_usec"], center_frequency_khz=m["center_frequency_khz"],
+                    sample_rate=m["sample_rate"], sample_bytes=2, sample_bits=16)
+    frames = fr.write(y)
+    h = hashlib.sha256()
+    for f in range(frames.shape[0]):
+        h.update(frames[f].tobytes())
+        h.update(orc.frame_encode(frames[f], m["nb_fec"]).tobytes())
+    return hashlib.sha256(y.tobytes()).hexdigest(), h.hexdigest(), int(frames.shape[0])
+
+
+def headline_golden():
+    """Whole-output digests of the BENCHMARKED launches: bench.py's 8 streams x 2^25 samples, configs[2] as one
+    stream of 2^27, and config 5's bank of 64 streams (x 2^22 here) -- inputs from signals.hash_noise (torch twin on the GPU),
+    decimated by the compiled reference itself."""
+    from oracle_lib import Oracle
+
+    ref, orc = Reference("eo1"), Oracle()
+    out = {"meta": HEADLINE_META, "flavour": "eo1"}
+    for name, seeds, log2n in (("bank8", list(range(1000, 1008)), 25), ("one27", [4000], 27), ("bank64", list(range(1000, 1064)), 22)):
+        dec, frm, nfr = [], [], []
+        for seed in seeds:
+            a, b, c = _headline_stream(ref, orc, 1 << log2n, seed)
+            dec.append(a); frm.append(b); nfr.append(c)
+            print("headline", name, seed, a[:12], b[:12], c, flush=True)
+        out[name] = {"seeds": seeds, "log2n": log2n, "dec_sha256": dec, "frames_sha256": frm, "nframes": nfr}
+    with open(os.path.join(HERE, "headline_golden.json"), "w") as f:
+        json.dump(out, f, indent=0)
 
 
 def fec_golden():
@@ -127,4 +197,9 @@ def fec_golden():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "headline":
+        headline_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "long":
+        long_golden()
+    else:
+        main()

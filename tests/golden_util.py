@@ -9,12 +9,14 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 class Golden:
-    def __init__(self):
-        self.arrays = np.load(os.path.join(HERE, "dsp_golden.npz"))
-        with open(os.path.join(HERE, "dsp_golden.json")) as f:
+    def __init__(self, name="dsp_golden"):
+        """name: dsp_golden (all entry points, 16384 samples) or dsp_golden_long (centred cascades, 65536 samples: long enough
+        for the matrix-core kernel at every ratio)"""
+        self.arrays = np.load(os.path.join(HERE, name + ".npz"))
+        with open(os.path.join(HERE, name + ".json")) as f:
             meta = json.load(f)
         self.cases = meta["cases"]
-        self.big = meta["big"]
+        self.big = meta.get("big", [])
 
     def input(self, case):
         x = self.arrays["in_" + case["input"]]
@@ -26,3 +28,9 @@ class Golden:
 
     def expected(self, case):
         return self.arrays[case["key"]]
+
+
+def headline():
+    """tests/golden/headline_golden.json: whole-output SHA-256 digests of the benchmarked launches (reference decimator)"""
+    with open(os.path.join(HERE, "headline_golden.json")) as f:
+        return json.load(f)

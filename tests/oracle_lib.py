@@ -193,12 +193,16 @@ class _FramerStruct(C.Structure):
     _fields_ = [("cur", C.c_uint8 * 512), ("slot", C.c_uint8 * (128 * 512)), ("tx_block_index", C.c_int),
                 ("sample_index", C.c_int), ("frame_count", C.c_uint16), ("center_frequency_khz", C.c_uint32),
                 ("sample_rate", C.c_uint32), ("sample_bytes", C.c_uint8), ("sample_bits", C.c_uint8),
-                ("nb_fec_blocks", C.c_uint8), ("tv_sec", C.c_uint32), ("tv_usec", C.c_uint32)]
+                ("nb_fec_blocks", C.c_uint8), ("tv_sec", C.c_uint32), ("tv_usec", C.c_uint32),
+                ("stamp_from_samples", C.c_int)]
 
 
 class OracleFramer:
     def __init__(self, orc, center_frequency_khz=435000, sample_rate=625000, sample_bytes=2, sample_bits=16,
-                 nb_fec_blocks=32, tv_sec=0, tv_usec=0):
+                 nb_fec_blocks=32, tv_sec=0, tv_usec=0, stamp_from_samples=1):
+        """stamp_from_samples=1 (the product's rule): (tv_sec, tv_usec) is the time of a write() call's first sample, the frames the
+        call opens are stamped by the sample clock from there; 0: the reference's literal behaviour with the test playing
+        gettimeofday (every frame a call opens carries tv_sec / tv_usec as they are)."""
         self.o = orc
         self.s = _FramerStruct()
         orc.lib.orc_framer_init(C.byref(self.s))
@@ -209,6 +213,7 @@ class OracleFramer:
         self.s.nb_fec_blocks = nb_fec_blocks
         self.s.tv_sec = tv_sec
         self.s.tv_usec = tv_usec
+        self.s.stamp_from_samples = stamp_from_samples
 
     def write(self, iq):
         """Returns completed frames as (n_frames, 128, 512) uint8."""

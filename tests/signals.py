@@ -69,3 +69,51 @@ ALL = {
     "zeros": zeros,
     "mixed": mixed,
 }
+
+
+# ---- counter-based noise with a torch twin: the same full-scale uniform int16 IQ stream on the CPU (numpy: golden
+# generation from the compiled reference) and on the GPU (torch: the `-m gpu` tests and bench.py make GiB-sized inputs
+# in milliseconds, no upload).  Sample i of stream `seed` = lowbias32(i ^ mix(seed)), I = low half, Q = high half.
+_HM = 0xFFFFFFFF
+
+
+def _seed_mix(seed):
+    return (int(seed) * 0x9E3779B1 + 0x85EBCA6B) & _HM
+
+
+def hash_noise(n, seed, start=0):
+    """(n, 2) int16, numpy.  Chunked so that the int64 temporaries stay small."""
+    out = np.empty((n, 2), dtype=np.int16)
+    flat = out.view(np.uint32).reshape(n)
+    sm = np.int64(_seed_mix(seed))
+    step = 1 << 22
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        x = (np.arange(start + a, start + b, dtype=np.int64) ^ sm) & _HM
+        x ^= x >> 16
+        x = (x * 0x7FEB352D) & _HM
+        x ^= x >> 15
+        x = (x * 0x846CA68B) & _HM
+        x ^= x >> 16
+        flat[a:b] = x.astype(np.uint32)
+    return out
+
+
+def hash_noise_torch(n, seed, device, start=0):
+    """(n, 2) int16 torch tensor on `device`, bit-identical to hash_noise(n, seed, start)."""
+    import torch
+
+    out = torch.empty((n, 2), dtype=torch.int16, device=device)
+    flat = out.view(torch.int32).reshape(n)
+    sm = _seed_mix(seed)
+    step = 1 << 24
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        x = (torch.arange(start + a, start + b, dtype=torch.int64, device=device) ^ sm) & _HM
+        x ^= x >> 16
+        x = (x * 0x7FEB352D) & _HM
+        x ^= x >> 15
+        x = (x * 0x846CA68B) & _HM
+        x ^= x >> 16
+        flat[a:b] = x.to(torch.int32)  # (wraps modulo 2^32: the same 32 bits)
+    return out

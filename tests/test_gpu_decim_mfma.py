@@ -1,5 +1,5 @@
 """GPU parity of the matrix-core decimator cascade (decim_mfma.hip): forced through the C ABI with
-SDRHIP_DECIM_PATH=mfma and short spans so that small inputs exercise many waves, the VALU head / tail pieces
+decim_path=mfma (sdrhip_ctx_set_option) and short spans so that small inputs exercise many waves, the VALU head / tail pieces
 and the bank state hand-over.  Bit-exact against the oracle (itself pinned to the compiled reference)."""
 import os
 
@@ -20,20 +20,17 @@ def ctx():
 
 
 @pytest.fixture()
-def mfma_path():
-    old = {k: os.environ.get(k) for k in ("SDRHIP_DECIM_PATH", "SDRHIP_MFMA_SPAN")}
-    os.environ["SDRHIP_DECIM_PATH"] = "mfma"
+def mfma_path(ctx):
+    """forces the matrix-core cascade with short spans on the module's context (sdrhip_ctx_set_option)"""
+    ctx.set_option("decim_path", "mfma")
 
     def span(n):
-        os.environ["SDRHIP_MFMA_SPAN"] = str(n)
+        ctx.set_option("mfma_span", n)
 
     span(1024)
     yield span
-    for k, v in old.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    ctx.set_option("decim_path", "auto")
+    ctx.set_option("mfma_span", 0)
 
 
 @pytest.mark.parametrize("signal", sorted(signals.ALL))
@@ -97,7 +94,7 @@ def test_mfma_default_span_planning_equals_valu(ctx, mfma_path, nstreams):
 
     import sdrdaemon_amd as sd
 
-    os.environ.pop("SDRHIP_MFMA_SPAN", None)
+    mfma_path(0)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(3 + nstreams)
     for n in ((70000, 300000 + 12) if nstreams > 3 else (70000, 300000 + 12, (1 << 21) + 76)):
@@ -105,7 +102,7 @@ def test_mfma_default_span_planning_equals_valu(ctx, mfma_path, nstreams):
         for log2 in (2, 4, 5, 6):
             res = []
             for path in ("mfma", "valu"):
-                os.environ["SDRHIP_DECIM_PATH"] = path
+                ctx.set_option("decim_path", path)
                 d = sd.Decimators(ctx, nstreams, 0)
                 cut = (n // 2 + 8) & ~3  # (device rows must stay 16-byte aligned)
                 a, _ = d.decimate(log2, 2, 16, x[:, :cut])

@@ -1,0 +1,172 @@
+"""The BENCHMARKED launches under the parity suite: exactly bench.py's calls (Decimators.decimate and
+RxPipe.process_view on device memory, the planner's own choice of kernel and spans) on bench.py's sizes, compared as WHOLE
+outputs with SHA-256 digests made from the compiled reference decimator (tests/golden/make_golden.py: headline_golden).
+Inputs come from the counter-based generator signals.hash_noise (numpy there, its torch twin here)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import signals
+from golden_util import Golden, headline
+
+pytestmark = pytest.mark.gpu
+
+H = headline()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import sdrdaemon_amd as sd
+
+    assert sd.device_count() > 0, "GPU tests need a GPU and libsdrhip.so"
+    return sd.Context(0)
+
+
+def _bank(name):
+    import torch
+
+    b = H[name]
+    return torch.stack([signals.hash_noise_torch(1 << b["log2n"], s, "cuda") for s in b["seeds"]]), b
+
+
+def _sha(t):
+    return hashlib.sha256(t.contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+def _rx(ctx, S):
+    import sdrdaemon_amd as sd
+
+    m = H["meta"]
+    return sd.RxPipe(ctx, S, log2decim=4, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=m["nb_fec"],
+                     center_frequency_khz=m["center_frequency_khz"], sample_rate=m["sample_rate"])
+
+
+def _check_frames(view, b):
+    fr = view.torch()
+    for s in range(fr.shape[0]):
+        assert fr.shape[1] == b["nframes"][s]
+        assert _sha(fr[s]) == b["frames_sha256"][s], ("frames of stream", s)
+
+
+def test_headline_bank_8_x_2p25(ctx):
+    """bench.py's step and its configs[1] line: 8 streams x 2^25 samples; the planner must pick the matrix-core kernel with
+    one wave per SIMD (124 waves per stream, spans of 33 792 samples) on an MI355X"""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    x, b = _bank("bank8")
+    S, n = x.shape[0], x.shape[1]
+    d = sd.Decimators(ctx, S, sd.HB_EO1)
+    y = torch.empty((S, n >> 4, 2), dtype=torch.int16, device=x.device)
+    d.decimate(4, sd.FC_CEN, 16, x, out=y)
+    ctx.synchronize()
+    plan = d.last_plan()
+    assert plan["path"] == "mfma" and plan["wps"] == 124 and plan["span"] == 33792, plan
+    for s in range(S):
+        assert _sha(y[s]) == b["dec_sha256"][s], ("decimated stream", s)
+    # a second call on the same handles continues the streams: same input again = a different output (history), still exact
+    # against the reference is checked by the chunked goldens; here: the pipe, fresh handles, whole frame stream
+    rx = _rx(ctx, S)
+    view = rx.process_view(x, tv_sec=H["meta"]["tv_sec"], tv_usec=H["meta"]["tv_usec"])
+    ctx.synchronize()
+    plan = rx.last_plan()
+    assert plan["path"] == "mfma" and plan["wps"] == 124 and plan["span"] == 33792, plan
+    _check_frames(view, b)
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_headline_rx_fused_and_separate_launches(ctx, fused):
+    """both plumbing variants of the Rx step (encoder inside the decimator's launch / separate launches): same frames"""
+    x, b = _bank("bank8")
+    ctx.set_option("rx_fused", fused)
+    try:
+        rx = _rx(ctx, x.shape[0])
+        view = rx.process_view(x, tv_sec=H["meta"]["tv_sec"], tv_usec=H["meta"]["tv_usec"])
+        ctx.synchronize()
+        _check_frames(view, b)
+    finally:
+        ctx.set_option("rx_fused", 1)
+
+
+def test_headline_one_stream_2p27(ctx):
+    """configs[2] literally: one stream of 2^27 samples through the decimator and through the Rx pipe, whole outputs"""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    x, b = _bank("one27")
+    d = sd.Decimators(ctx, 1, sd.HB_EO1)
+    y = torch.empty((1, x.shape[1] >> 4, 2), dtype=torch.int16, device=x.device)
+    d.decimate(4, sd.FC_CEN, 16, x, out=y)
+    ctx.synchronize()
+    assert d.last_plan()["path"] == "mfma"
+    assert _sha(y[0]) == b["dec_sha256"][0]
+    del y
+    rx = _rx(ctx, 1)
+    view = rx.process_view(x, tv_sec=H["meta"]["tv_sec"], tv_usec=H["meta"]["tv_usec"])
+    ctx.synchronize()
+    _check_frames(view, b)
+
+
+def test_headline_bank_64(ctx):
+    """config 5's bank on one GPU (bench.py --streams 64 at 2^22 samples per stream): 64 streams, whole outputs"""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    x, b = _bank("bank64")
+    S, n = x.shape[0], x.shape[1]
+    d = sd.Decimators(ctx, S, sd.HB_EO1)
+    y = torch.empty((S, n >> 4, 2), dtype=torch.int16, device=x.device)
+    d.decimate(4, sd.FC_CEN, 16, x, out=y)
+    ctx.synchronize()
+    assert d.last_plan()["path"] == "mfma"
+    for s in range(S):
+        assert _sha(y[s]) == b["dec_sha256"][s], s
+    rx = _rx(ctx, S)
+    view = rx.process_view(x, tv_sec=H["meta"]["tv_sec"], tv_usec=H["meta"]["tv_usec"])
+    ctx.synchronize()
+    _check_frames(view, b)
+
+
+@pytest.mark.parametrize("path", ["valu", "mfma"])
+def test_reference_goldens_through_both_kernels(ctx, path):
+    """Reference goldens of the centred cascades through BOTH kernels.  (a) the 16384-sample goldens of decimate4 / 8 / 16_cen
+    in ONE call (their chunks are multiples of 16, so the reference's chunked output is the single-call output) with spans of
+    256 << (L - 2): the matrix-core kernel engages (asserted); (b) the 65536-sample goldens of decimate4 .. 64_cen, one call
+    and a ragged two-call split (state handed over through the VALU head / tail pieces)."""
+    import sdrdaemon_amd as sd
+
+    ctx.set_option("decim_path", path)
+    try:
+        G = Golden()
+        n = 0
+        for case in G.cases:
+            if case["kind"] != "decimate" or case["fcpos"] != 2 or not 2 <= case["log2"] <= 4:
+                continue
+            ctx.set_option("mfma_span", 64 << case["log2"])
+            d = sd.Decimators(ctx, 1, case["bias"])
+            o, ss = d.decimate(case["log2"], 2, case["sample_size"], G.input(case))
+            assert d.last_plan()["path"] == path, (case["key"], d.last_plan())
+            assert ss == case["sample_size_out"] and np.array_equal(o, G.expected(case)), case["key"]
+            n += 1
+        assert n == 2 * 3 * 7
+        GL = Golden("dsp_golden_long")
+        for case in GL.cases:
+            ctx.set_option("mfma_span", 64 << case["log2"])
+            x = GL.input(case)
+            d = sd.Decimators(ctx, 1, case["bias"])
+            pos, outs, used = 0, [], []
+            for c in case["chunks"]:
+                o, ss = d.decimate(case["log2"], 2, 16, x[pos:pos + c])
+                used.append(d.last_plan()["path"])
+                outs.append(o)
+                pos += c
+            assert np.array_equal(np.concatenate(outs), GL.expected(case)), case["key"]
+            if len(case["chunks"]) == 1:
+                assert used == [path], (case["key"], used)
+    finally:
+        ctx.set_option("decim_path", "auto")
+        ctx.set_option("mfma_span", 0)

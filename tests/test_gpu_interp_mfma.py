@@ -1,5 +1,5 @@
 """GPU parity of the matrix-core interpolator cascade (interp_mfma.hip): forced through the C ABI with
-SDRHIP_INTERP_PATH=mfma and short spans so that small inputs exercise many waves, the VALU head / tail segments and
+interp_path=mfma (sdrhip_ctx_set_option) and short spans so that small inputs exercise many waves, the VALU head / tail segments and
 the bank state hand-over.  Bit-exact against the oracle (itself pinned to the compiled reference)."""
 import os
 
@@ -20,21 +20,16 @@ def ctx():
 
 
 @pytest.fixture()
-def mfma_path():
-    keys = ("SDRHIP_INTERP_PATH", "SDRHIP_INTERP_SPAN")
-    old = {k: os.environ.get(k) for k in keys}
-    os.environ["SDRHIP_INTERP_PATH"] = "mfma"
+def mfma_path(ctx):
+    ctx.set_option("interp_path", "mfma")
 
     def span(n):
-        os.environ["SDRHIP_INTERP_SPAN"] = str(n)
+        ctx.set_option("interp_span", n)
 
     span(64)
     yield span
-    for k, v in old.items():
-        if v is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = v
+    ctx.set_option("interp_path", "valu")
+    ctx.set_option("interp_span", 0)
 
 
 @pytest.mark.parametrize("signal", sorted(signals.ALL))
@@ -73,14 +68,14 @@ def test_mfma_stream_bank_equals_valu(ctx, mfma_path):
 
     import sdrdaemon_amd as sd
 
-    os.environ.pop("SDRHIP_INTERP_SPAN", None)
+    mfma_path(0)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(7)
     x = torch.randint(-32768, 32768, (3, (1 << 20) + 40, 2), generator=g, device=dev, dtype=torch.int16)
     for log2 in (2, 3, 4):
-        os.environ["SDRHIP_INTERP_PATH"] = "mfma"
+        ctx.set_option("interp_path", "mfma")
         a = sd.Interpolators(ctx, 3).interpolate(log2, x)
-        os.environ["SDRHIP_INTERP_PATH"] = "valu"
+        ctx.set_option("interp_path", "valu")
         b = sd.Interpolators(ctx, 3).interpolate(log2, x)
         ctx.synchronize()
         assert torch.equal(a, b), log2

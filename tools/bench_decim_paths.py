@@ -42,11 +42,8 @@ for L in (6, 5, 4, 3, 2) if ONLY is None else (int(ONLY[2]),):
     ref = None
     for path, span in ((("valu", 0), ("mfma", 0), ("mfma", 8192), ("mfma", 16384), ("mfma", 32768), ("mfma", 65536)) if ONLY is None
                        else ((ONLY[0], int(ONLY[1])),)):
-        os.environ["SDRHIP_DECIM_PATH"] = path
-        if span:
-            os.environ["SDRHIP_MFMA_SPAN"] = str(span)
-        else:
-            os.environ.pop("SDRHIP_MFMA_SPAN", None)
+        ctx.set_option("decim_path", path)
+        ctx.set_option("mfma_span", span)
         d = sd.Decimators(ctx, S, 0)
         ms = timed(lambda: d.decimate(L, 2, 16, x, out=out))
         d2 = sd.Decimators(ctx, S, 0)

@@ -42,11 +42,8 @@ for L in (4, 3, 2) if ONLY is None else (int(ONLY[2]),):
     out = torch.empty((S, n_out, 2), dtype=torch.int16, device=dev)
     ref = None
     for path, span in ((("valu", 0), ("mfma", 0), ("mfma", 1024), ("mfma", 2048), ("mfma", 8192)) if ONLY is None else ((ONLY[0], int(ONLY[1])),)):
-        os.environ["SDRHIP_INTERP_PATH"] = path
-        if span:
-            os.environ["SDRHIP_INTERP_SPAN"] = str(span)
-        else:
-            os.environ.pop("SDRHIP_INTERP_SPAN", None)
+        ctx.set_option("interp_path", path)
+        ctx.set_option("interp_span", span)
         d = sd.Interpolators(ctx, S)
         ms = timed(lambda: d.interpolate(L, x, out=out))
         y = sd.Interpolators(ctx, S).interpolate(L, x)

@@ -21,7 +21,7 @@ for S, logn in ((1, 20), (1, 21), (1, 22), (1, 23), (1, 24), (1, 25), (8, 20), (
     out = torch.empty((S, n >> L, 2), dtype=torch.int16, device=dev)
     res = []
     for path in ("valu", "mfma"):
-        os.environ["SDRHIP_DECIM_PATH"] = path
+        ctx.set_option("decim_path", path)
         d = sd.Decimators(ctx, S, 0)
         for _ in range(20):
             d.decimate(L, 2, 16, x, out=out)

@@ -47,8 +47,9 @@ while time.time() - t0 < budget:
     what = rs.choice(["decim", "interp", "rx", "tx", "fec"], p=[0.3, 0.2, 0.2, 0.1, 0.2])
     # decimator kernel selection per iteration: the VALU cascade, the matrix-core cascade (short spans so that small
     # inputs run many waves + the VALU head / tail pieces), or the library's own choice
-    os.environ["SDRHIP_DECIM_PATH"] = str(rs.choice(["auto", "valu", "mfma", "mfma"]))
-    os.environ["SDRHIP_MFMA_SPAN"] = str(1024 * int(rs.choice([1, 1, 2, 3, 5, 16])))
+    ctx.set_option("decim_path", str(rs.choice(["auto", "valu", "mfma", "mfma"])))
+    ctx.set_option("mfma_span", 1024 * int(rs.choice([1, 1, 2, 3, 5, 16])))
+    ctx.set_option("rx_fused", int(rs.randint(0, 2)))
     if what == "decim":
         S = int(rs.randint(1, 4))
         bias = int(rs.randint(0, 2))

@@ -20,16 +20,13 @@ S, n, L = 8, 1 << 25, 4
 x = torch.randint(-32768, 32768, (S, n, 2), generator=g, device=dev, dtype=torch.int16)
 out = torch.empty((S, n >> L, 2), dtype=torch.int16, device=dev)
 frames = torch.randint(0, 256, (1040, 128, 512), generator=g, device=dev, dtype=torch.uint8)
-os.environ["SDRHIP_DECIM_PATH"] = "mfma"
+ca.set_option("decim_path", "mfma")
 d = sd.Decimators(ca, S, 0)
 K = 60
 
 
 def run(span, mode):
-    if span:
-        os.environ["SDRHIP_MFMA_SPAN"] = str(span)
-    else:
-        os.environ.pop("SDRHIP_MFMA_SPAN", None)
+    ca.set_option("mfma_span", span)
     for warm in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
