@@ -259,12 +259,132 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
             pk[r] = final_pack(comp ? other : o, comp ? o : other, oc.norm, oc.trunk);
         }
         unsigned *dst = oc.store ? oc.p : oc.dump;
+#if MF_ABL & 128 // no global stores
+        asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(dst));
+#else
         *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
+#endif
         oc.p += oc.store ? 16 : 0;
     }
 }
 
-template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw)
+// front end of a step: the lane's 16 raw bytes (four samples x, y, z, w: y, w are odd-plane entries, x, z even-plane entries
+// 2q, 2q + 1 of their half block) -> limb bytes of the stage-0 window
+struct MfFront {
+    unsigned sel_own, sel_oth, sel_lo, sel_hi;
+    unsigned ev_lo, ev_hi; // even entries of the previous step (limbs made signed)
+};
+template <int NS, int I> __device__ __forceinline__ void mf_front(MfState<NS> &st, const MfConst &k, MfFront &f, const uint4_t r)
+{
+    constexpr int i = I;
+    const unsigned ao = perm(r.w, r.y, f.sel_own), ae = perm(r.z, r.x, f.sel_own);
+    const unsigned xo = perm(r.w, r.y, f.sel_oth), xe = perm(r.z, r.x, f.sel_oth);
+    const unsigned yo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xo, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+    const unsigned ye = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xe, 0xB1, 0xf, 0xf, true);
+    st.O[0][0][i & 3] = (int)(perm(ao, yo, f.sel_lo) ^ 0x80808080u);
+    st.O[0][1][i & 3] = (int)perm(ao, yo, f.sel_hi);
+    const unsigned cur_lo = perm(ae, ye, f.sel_lo) ^ 0x80808080u, cur_hi = perm(ae, ye, f.sel_hi);
+    // even entries of tile i: those of the previous step, and the first one of this step (lanes kq = 0)
+    st.O[0][0][(i + 1) & 3] = (int)perm(cur_lo, f.ev_lo, k.selA);
+    st.O[0][1][(i + 1) & 3] = (int)perm(cur_hi, f.ev_hi, k.selA);
+    f.ev_lo = cur_lo; f.ev_hi = cur_hi;
+}
+
+// ---- LDS-DMA input ring (round 3).  Measured on the register ring above (8 x 2^25, decimate16): arithmetic alone 0.201 ms, the
+// memory skeleton alone 0.206-0.238 ms, both together 0.240 ms: with ONE wave per SIMD nothing covers a wave's s_waitcnt (33 %
+// of its cycles), and a second wave per SIMD does not help because the SIMD's issue port is what the arithmetic saturates.  So
+// the loads leave the wave's instruction stream's critical path altogether: global_load_lds_dwordx4 copies 1 KiB per
+// instruction straight into LDS (no VGPRs, nothing for hipcc to drain at the loop top), 24 steps = 24 KiB per wave ahead.
+//  * a DMA covers ONE span for 8 steps (1 KiB contiguous: eight full 128-byte lines touched once, against 32 line visits for
+//    the span-strided register loads); a group = 8 steps = 8 DMAs (one per span), the ring holds 4 groups.
+//  * step i issues DMA (group i / 8 + 3, span i % 8); the group needed next is waited for once per 8 steps with
+//    s_waitcnt vmcnt(15): fifteen DMAs were issued after its last one (loads return in order; stores in between only make
+//    the wait conservative).
+//  * a lane reads its 16 bytes of a step back with one ds_read_b128 (issued one step ahead).  The 1-KiB block of span p
+//    starts 72 p + 2 (p >> 2) sixteen-byte units into the group: the sixteen lanes of every ds_read_b128 service group
+//    (MI355X_MICROARCH.md, LDS table) then hit sixteen distinct 4-bank columns.
+#ifndef MF_DMA
+#define MF_DMA 1
+#endif
+constexpr int MF_GROUP_BYTES = 9216;             // 8 blocks of 1 KiB + their skew
+constexpr int MF_WAVE_RING = 4 * MF_GROUP_BYTES; // bytes of LDS per wave
+__host__ __device__ constexpr bool mf_dma_applies(int ns) { return MF_DMA && ns >= 4; } // (period of 32 steps; one workgroup per CU)
+__host__ __device__ constexpr int mf_block_units(int p) { return 72 * p + 2 * (p >> 2); }
+
+template <int SLOT, int D> __device__ __forceinline__ void mf_dma_issue(unsigned ring, unsigned voff, unsigned long long span_base)
+{
+    constexpr int off = SLOT * MF_GROUP_BYTES + 16 * mf_block_units(D);
+    // M0 = LDS byte address of the block (wave-uniform); the lanes' 16 bytes land at M0 + 16 * lane
+#ifndef MF_NT
+#define MF_NT 1
+#endif
+#if MF_NT // streamed once: non-temporal (tools/dma_probe.hip: 7.1 TB/s against 6.2 TB/s with the default policy)
+    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3 nt" ::"v"(voff), "s"(ring), "n"(off), "s"(span_base) : "memory", "scc");
+#else
+    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3" ::"v"(voff), "s"(ring), "n"(off), "s"(span_base) : "memory", "scc");
+#endif
+}
+
+template <int NS>
+__device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st, const MfConst &k, MfOut &oc, MfFront &fr, unsigned lds_addr,
+                                            const char *wbase, size_t S, int nper, int WP, int lane, int p, int comp, int q)
+{
+    constexpr int P = mf_period<NS>();
+    static_assert(P == 32, "the ring turns once per period");
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned ring = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr + (unsigned)wv * MF_WAVE_RING));
+    unsigned long long sb[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const unsigned long long v = (unsigned long long)(wbase + (size_t)d * S * 4);
+        sb[d] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    }
+    // what this lane reads back: bytes 128 j + 64 comp + 16 q of step j of span p
+    const __attribute__((address_space(3))) char *lrd =
+        (const __attribute__((address_space(3))) char *)(size_t)(ring + 16u * (unsigned)(mf_block_units(0) + 72 * p + 2 * (p >> 2) + 4 * comp + q));
+    unsigned voff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) voff[g] = 16u * (unsigned)lane + 1024u * (unsigned)(g == 3 ? 3 : g + 4);
+    {
+        // groups 0, 1, 2 of the ring
+        unsigned v0 = 16u * (unsigned)lane;
+        mf_static_for<24>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            mf_dma_issue<i / 8, i % 8>(ring, v0 + 1024u * (unsigned)(i / 8), sb[i % 8]);
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // group 0 has landed
+    uint4_t r = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd);
+    for (int per = 0; per < nper; ++per) {
+        oc.store = per >= WP;
+        mf_static_for<P>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int i1 = (i + 1) % P;
+            if constexpr (i1 % 8 == 0) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); // the next group has landed
+#if MF_ABL & 1024 // (timing experiment: no read-back from the ring)
+            uint4_t rn = r;
+            asm volatile("" : "+v"(rn));
+#else
+            const uint4_t rn = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd + (i1 / 8) * MF_GROUP_BYTES + 128 * (i1 % 8));
+#endif
+            constexpr int g = (i / 8 + 3) % 4;
+#if !(MF_ABL & 512) // (timing experiment: no DMAs in the loop)
+            mf_dma_issue<g, i % 8>(ring, voff[g], sb[i % 8]);
+#endif
+            if constexpr (i % 8 == 7) voff[g] += 4096u;
+#if MF_ABL & 16
+            asm volatile("" : "+v"(st.O[0][0]), "+v"(st.O[0][1]) : "v"(r));
+#else
+            mf_front<NS, i>(st, k, fr, r);
+#endif
+            mf_stage<NS, 0, i>(st, k, oc, comp);
+            r = rn;
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no DMA may outlive the workgroup's LDS allocation
+}
+
+template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, unsigned lds_addr)
 {
     constexpr int L = NS;
     constexpr int P = mf_period<NS>();  // first-stage steps per period of the unrolled schedule
@@ -325,16 +445,29 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
     }
 
     // byte selectors: a sample dword is {I lo, I hi, Q lo, Q hi}
-    const unsigned sel_own = comp ? 0x07030602u : 0x05010400u; // {lo(a), lo(b), hi(a), hi(b)} of this lane's component
-    const unsigned sel_oth = comp ? 0x05010400u : 0x07030602u; // ... of the neighbour's
+    MfFront fr;
+    fr.sel_own = comp ? 0x07030602u : 0x05010400u; // {lo(a), lo(b), hi(a), hi(b)} of this lane's component
+    fr.sel_oth = comp ? 0x05010400u : 0x07030602u; // ... of the neighbour's
     // {own half, received half} -> {first, second} half of the block: the I lane loaded the first half
-    const unsigned sel_lo = comp ? 0x05040100u : 0x01000504u, sel_hi = comp ? 0x07060302u : 0x03020706u;
-    unsigned ev_lo = 0u, ev_hi = 0u; // even entries of the previous step (limbs made signed)
+    fr.sel_lo = comp ? 0x05040100u : 0x01000504u; fr.sel_hi = comp ? 0x07060302u : 0x03020706u;
+    fr.ev_lo = 0u; fr.ev_hi = 0u;
+#if MF_DMA
+    if constexpr (mf_dma_applies(NS)) {
+        mf_loop_dma<NS>(a, st, k, oc, fr, lds_addr, wbase, S, nper, WP, lane, p, comp, q);
+        return;
+    }
+#endif
     uint4_t ld[D];
     // step g of this lane's column pair: 128 bytes at src + 128 g.  No bounds handling: the loads run D steps past the
     // end of the span, i.e. into the next span or (last span of a stream) the first 32 D samples of the tail that
     // plan_decimate_mfma() guarantees
     const char *src = wbase + loff;
+#if MF_ABL & 256 // timing experiment (wrong data): wave-contiguous loads, 1 KiB per instruction, same bytes per wave in total
+    src = wbase + 16 * lane; // the wave walks its 8 spans' worth of bytes as one contiguous region, 1 KiB per step
+#define MF_LDSTRIDE 1024
+#else
+#define MF_LDSTRIDE 128
+#endif
 #ifdef MF_SKEW // experiment: de-phase the waves' addresses (wrong data)
     src += (size_t)(gw % MF_SKEW) * (4096 / MF_SKEW);
 #endif
@@ -342,7 +475,7 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
     // operations exactly only inside a basic block, drains the ring with a vmcnt(0) at the top of every period: same
     // launch time, 0.255 ms both ways, and the register allocator may copy an asm load's destination before the wait.)
 #pragma unroll
-    for (int d = 0; d < D; ++d) ld[d] = *reinterpret_cast<const uint4_t *>(src + 128 * d);
+    for (int d = 0; d < D; ++d) ld[d] = *reinterpret_cast<const uint4_t *>(src + MF_LDSTRIDE * d);
 
     for (int per = 0; per < nper; ++per) {
         oc.store = per >= WP;
@@ -350,35 +483,30 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
             constexpr int i = decltype(ic)::value;
             constexpr int slot = i % D;
             const uint4_t r = ld[slot];
-            ld[slot] = *reinterpret_cast<const uint4_t *>(src + 128 * (i + D));
+#if MF_ABL & 512 // timing experiment (wrong data): no loads in the loop, the arithmetic runs on stale registers
+            asm volatile("" : "+v"(ld[slot]));
+#else
+            ld[slot] = *reinterpret_cast<const uint4_t *>(src + MF_LDSTRIDE * (i + D));
+#endif
 #if MF_ABL & 16
             asm volatile("" : "+v"(st.O[0][0]), "+v"(st.O[0][1]) : "v"(r));
             mf_stage<NS, 0, i>(st, k, oc, comp);
             return;
 #endif
-            // four samples x, y, z, w: y, w are odd-plane entries, x, z even-plane entries (2q, 2q + 1 of their half block)
-            const unsigned ao = perm(r.w, r.y, sel_own), ae = perm(r.z, r.x, sel_own);
-            const unsigned xo = perm(r.w, r.y, sel_oth), xe = perm(r.z, r.x, sel_oth);
-            const unsigned yo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xo, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
-            const unsigned ye = (unsigned)__builtin_amdgcn_update_dpp(0, (int)xe, 0xB1, 0xf, 0xf, true);
-            st.O[0][0][i & 3] = (int)(perm(ao, yo, sel_lo) ^ 0x80808080u);
-            st.O[0][1][i & 3] = (int)perm(ao, yo, sel_hi);
-            const unsigned cur_lo = perm(ae, ye, sel_lo) ^ 0x80808080u, cur_hi = perm(ae, ye, sel_hi);
-            // even entries of tile i: those of the previous step, and the first one of this step (lanes kq = 0)
-            st.O[0][0][(i + 1) & 3] = (int)perm(cur_lo, ev_lo, k.selA);
-            st.O[0][1][(i + 1) & 3] = (int)perm(cur_hi, ev_hi, k.selA);
-            ev_lo = cur_lo; ev_hi = cur_hi;
+            mf_front<NS, i>(st, k, fr, r);
             mf_stage<NS, 0, i>(st, k, oc, comp);
         });
-        src += 128 * P;
+        src += MF_LDSTRIDE * P;
     }
 }
 
 // grid.x = the matrix-core workgroups (four waves = four groups of 8 spans each), then nstreams * mf_npieces VALU
 // workgroups (head + tail pieces of every stream)
-template <int L, bool PACK16> __global__ __launch_bounds__(NT, MF_WAVES) void decim_mfma_kernel(DecimArgs a)
+template <int L, bool PACK16> __global__ __launch_bounds__(NT, mf_dma_applies(L) ? 1 : MF_WAVES) void decim_mfma_kernel(DecimArgs a)
 {
-    __shared__ __attribute__((aligned(16))) int lds[DecimLds<L, 2, PACK16>::dwords]; // the VALU pieces' stage buffers
+    // the VALU pieces' stage buffers, or (matrix-core workgroups of the long cascades) the four waves' LDS-DMA rings
+    constexpr int LDSDW = mf_dma_applies(L) && 4 * MF_WAVE_RING / 4 > DecimLds<L, 2, PACK16>::dwords ? 4 * MF_WAVE_RING / 4 : DecimLds<L, 2, PACK16>::dwords;
+    __shared__ __attribute__((aligned(16))) int lds[LDSDW];
     // The matrix-core workgroups come FIRST in the grid: the dispatcher deals the first workgroups of a launch across
     // the empty CUs, and with one wave per SIMD (plan_decimate_mfma) the launch takes as long as its fullest CU: a CU
     // that got two of them while the short VALU pieces held slots elsewhere doubled the time of the whole launch.
@@ -399,7 +527,7 @@ template <int L, bool PACK16> __global__ __launch_bounds__(NT, MF_WAVES) void de
     }
     const int gw = __builtin_amdgcn_readfirstlane(bx * 4 + (int)(threadIdx.x >> 6));
     if (gw >= a.nstreams * a.mf_wps) return;
-    mf_wave<L>(a, gw);
+    mf_wave<L>(a, gw, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds);
 }
 
 template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream_t stream)
@@ -467,7 +595,8 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
     if (wps == 0 || wps > 0x7fffffffu / (size_t)nstreams) return false;
     if (8 * S * 4 >= 0xffffffffu) return false;   // lane offsets inside a wave are 32 bits
     size_t tail_start = head + wps * 8 * S;
-    if (n_used - tail_start < 256) { // the waves read up to 256 samples past their last span (prefetch)
+    // the waves read past their last span: 8 steps of register prefetch (256 samples) or three groups of the LDS-DMA ring (768)
+    if (n_used - tail_start < (mf_dma_applies(log2decim) ? 1024u : 256u)) {
         if (--wps == 0) return false;
         tail_start = head + wps * 8 * S;
     }
