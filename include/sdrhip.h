@@ -233,6 +233,15 @@ int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in, size_t i
                       uint32_t tv_usec, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames,
                       int mem);
 size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in);
+/* Pipelined mode (off by default).  The reference's sink is asynchronous as well: UDPSinkFEC::write returns at once and the
+ * transmit thread encodes and sends a frame later (UDPSinkFEC.cpp:193-211).  With on != 0 a sdrhip_rx_process call DELIVERS
+ * (frames_out, *n_frames, sdrhip_rx_frames_view) the frames that the PREVIOUS call completed; their recovery blocks are computed
+ * by encoder workgroups that ride in this call's decimator launch (one launch instead of two, the encoder fills the issue
+ * slots the decimator's waves leave empty).  Same bytes, one call later.  sdrhip_rx_flush encodes and delivers the frames the
+ * last call completed (end of stream, before switching the mode off).  frames_out of a pipelined call must hold
+ * sdrhip_rx_max_frames() frames per stream. */
+int sdrhip_rx_set_pipelined(sdrhip_rx *rx, int on);
+int sdrhip_rx_flush(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames, int mem);
 /* the decimator launch of the last sdrhip_rx_process call (see sdrhip_decimators_last_plan) */
 int sdrhip_rx_last_plan(const sdrhip_rx *rx, sdrhip_decim_plan *out);
 /* Zero-copy alternative for device-side consumers (what transmitUDP does when it sends straight

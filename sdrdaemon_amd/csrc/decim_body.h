@@ -349,7 +349,7 @@ __device__ __forceinline__ void decim_piece(const DecimArgs &a, int *lds, int st
         const size_t left = rend - p;
         if (left >= (size_t)PRAW) { // full pass (wave-uniform): no per-lane bounds checks
 #pragma unroll
-            for (int n = 0; n < NLD; ++n) ld[n] = *reinterpret_cast<const uint4_t *>(src + 4 * (tid + n * NT));
+            for (int n = 0; n < NLD; ++n) ld[n] = SDRHIP_STREAM_LOAD(reinterpret_cast<const uint4_t *>(src + 4 * (tid + n * NT)));
             return;
         }
         const unsigned rem = (unsigned)left;
@@ -358,7 +358,7 @@ __device__ __forceinline__ void decim_piece(const DecimArgs &a, int *lds, int st
             const unsigned q = (unsigned)(tid + n * NT);
             uint4_t v = (uint4_t){0u, 0u, 0u, 0u};
             if (4 * q + 3 < rem) {
-                v = *reinterpret_cast<const uint4_t *>(src + 4 * q);
+                v = SDRHIP_STREAM_LOAD(reinterpret_cast<const uint4_t *>(src + 4 * q));
             } else if (4 * q < rem) { // ragged tail of a call whose length is not a multiple of 4
                 v.x = src[4 * q];
                 if (4 * q + 1 < rem) v.y = src[4 * q + 1];

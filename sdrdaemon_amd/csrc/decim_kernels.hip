@@ -110,7 +110,7 @@ __global__ void decim_simple_kernel(int log2decim, int fcpos, const int16_t *in,
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (log2decim == 0) {
         for (size_t i = g; i < n_in; i += (size_t)gridDim.x * blockDim.x) {
-            unsigned v = src[i];
+            unsigned v = SDRHIP_STREAM_LOAD(src + i);
             int a = (short)(v & 0xffff), b = (int)v >> 16;
             dst[i] = (((unsigned)a << norm) & 0xffffu) | (((unsigned)b << norm) << 16);
         }
@@ -123,7 +123,7 @@ __global__ void decim_simple_kernel(int log2decim, int fcpos, const int16_t *in,
             if (log2decim == 1 && 2 * q < n_resize) dst[2 * q] = 0;
             continue;
         }
-        const unsigned v0 = src[4 * q], v1 = src[4 * q + 1], v2 = src[4 * q + 2], v3 = src[4 * q + 3];
+        const unsigned v0 = SDRHIP_STREAM_LOAD(src + 4 * q), v1 = SDRHIP_STREAM_LOAD(src + 4 * q + 1), v2 = SDRHIP_STREAM_LOAD(src + 4 * q + 2), v3 = SDRHIP_STREAM_LOAD(src + 4 * q + 3);
         const int I0 = (short)(v0 & 0xffff), Q0 = (int)v0 >> 16, I1 = (short)(v1 & 0xffff), Q1 = (int)v1 >> 16;
         const int I2 = (short)(v2 & 0xffff), Q2 = (int)v2 >> 16, I3 = (short)(v3 & 0xffff), Q3 = (int)v3 >> 16;
         if (log2decim == 1) {

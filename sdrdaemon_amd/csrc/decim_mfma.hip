@@ -139,6 +139,7 @@ struct MfOut {
     unsigned *dump;       // 16 bytes per lane that swallow the stores of the warm-up period (no branch in the loop body)
     int store;            // 0 during warm-up
     int norm, trunk;
+    unsigned hold[4];     // the packed outputs of the even tile of a pair (stores go out as full 128-byte lines, see mf_stage)
 };
 
 __device__ __forceinline__ int sbfe16(unsigned v, int off) { return (int)__builtin_amdgcn_sbfe((int)v, (unsigned)off, 16u); }
@@ -258,13 +259,42 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
             const int other = __builtin_amdgcn_update_dpp(0, o, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
             pk[r] = final_pack(comp ? other : o, comp ? o : other, oc.norm, oc.trunk);
         }
-        unsigned *dst = oc.store ? oc.p : oc.dump;
+#ifndef MF_PAIR
+#define MF_PAIR 0 // measured: no difference (0.2359 against 0.2352 ms); the cost of the stores is not their granularity
+#endif
+        // Lanes n = 2p (I) and 2p + 1 (Q) hold the same four packed samples.  Stored as they come, a tile is 64 bytes per span,
+        // written twice.  On the memory skeleton of this kernel those 67 MB of scattered writes cost as much as 250 MB of reads
+        // (0.224 ms against 0.171 ms with the stores aimed at one cached line), although the same stores ALONE take 0.01 ms
+        // (tools/dma_probe.hip): it is the mix of the write stream with 5 TB/s of reads.  Experiment kept behind MF_PAIR: two tiles
+        // make one store (the I lane writes the even tile's samples, the Q lane the odd tile's: one full 128-byte line per span and
+        // instruction, nothing written twice) -- same launch time, so granularity is not what the writes cost; off by default.
+        constexpr int NF = mf_period<NS>() >> (NS - 1 - mf_nfixed(NS)) >> mf_nfixed(NS); // final tiles per period
+        if constexpr (MF_PAIR && NF % 2 == 0) {
+            if constexpr ((I & 1) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oc.hold[r] = pk[r];
+                return;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = comp ? pk[r] : oc.hold[r];
+            }
+        }
+        constexpr bool PAIRED = MF_PAIR && NF % 2 == 0;
+        unsigned *dst = oc.store ? oc.p + (PAIRED && comp ? 16 : 0) : oc.dump;
+#if MF_ABL & 2048 // (timing experiment: every store goes to the dump slot)
+        dst = oc.dump;
+#endif
 #if MF_ABL & 128 // no global stores
         asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(dst));
+#elif defined(MF_STV) // store experiments: 1 = only the I lane of a pair stores, 2 = non-temporal, 3 = both
+        if (!(MF_STV & 1) || !comp) {
+            if (MF_STV & 2) __builtin_nontemporal_store((uint4_t){pk[0], pk[1], pk[2], pk[3]}, reinterpret_cast<uint4_t *>(dst));
+            else *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
+        }
 #else
         *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
 #endif
-        oc.p += oc.store ? 16 : 0;
+        oc.p += oc.store ? (PAIRED ? 32 : 16) : 0;
     }
 }
 
@@ -323,6 +353,102 @@ template <int SLOT, int D> __device__ __forceinline__ void mf_dma_issue(unsigned
 #else
     asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3" ::"v"(voff), "s"(ring), "n"(off), "s"(span_base) : "memory", "scc");
 #endif
+}
+
+// ---- loader wave (round 3, second step).  With the DMAs in the compute waves' own instruction stream a step still pays ~50
+// cycles of issue per DMA and ~10 % of s_waitcnt (arithmetic alone: 0.19 ms; with its DMAs: 0.24 ms).  So a FIFTH wave per
+// workgroup does nothing but feed the four rings, and the compute waves contain no load at all: every 8 steps (one group) all
+// five waves meet at one s_barrier -- in front of barrier k + 1 the loader has issued the 32 DMAs of group k + 3 (four waves x
+// eight spans, into the slot the compute waves left at barrier k) and has waited (vmcnt) until group k + 1 has landed; behind
+// it the compute waves start group k + 1.  The four compute waves run the same instruction stream on their own SIMDs, the
+// loader shares SIMD 0 with one of them and issues on other ports (scalar / vector memory).
+#ifndef MF_LOADER
+#define MF_LOADER 0 // measured (tools/exp16.sh, 5 interleaved rounds): 0.244-0.252 ms against 0.232-0.238 ms with the DMAs in the compute waves
+#endif
+constexpr int MF_NT5 = 320; // threads of a matrix-core workgroup with a loader wave
+
+__device__ __forceinline__ void mf_dma_issue_rt(unsigned m0v, unsigned voff, unsigned long long span_base)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" ::"v"(voff), "s"(m0v), "s"(span_base) : "memory");
+}
+
+// ngroups = groups of 8 steps every compute wave of the launch walks (4 per period)
+__device__ __forceinline__ void mf_loader(const DecimArgs &a, int bx, unsigned lds_addr, size_t W, int ngroups)
+{
+    const int lane = threadIdx.x & 63;
+    const int total = a.nstreams * a.mf_wps;
+    const size_t S = a.mf_span;
+    unsigned long long base[4];
+    int live = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int gw = bx * 4 + w;
+        if (gw < total) {
+            const int stream = gw / a.mf_wps, ws = gw - stream * a.mf_wps;
+            base[w] = (unsigned long long)(reinterpret_cast<const char *>(a.in) + ((size_t)stream * a.in_stride + a.mf_head + (size_t)ws * 8 * S - W) * 4);
+            live = w + 1;
+        } else {
+            base[w] = 0;
+        }
+    }
+    const unsigned ring0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    const unsigned long long sstep = (unsigned long long)S * 4;
+    auto issue_group = [&](int g) { // the 8 DMAs of group g of every live compute wave
+        const unsigned voff = 16u * (unsigned)lane + 1024u * (unsigned)g;
+        const unsigned slot = ring0 + (unsigned)(g & 3) * MF_GROUP_BYTES;
+        for (int w = 0; w < live; ++w) {
+            unsigned long long sb = base[w];
+            unsigned m = slot + (unsigned)w * MF_WAVE_RING;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                mf_dma_issue_rt(m + 16u * (unsigned)mf_block_units(d), voff, sb);
+                sb += sstep;
+            }
+        }
+    };
+    issue_group(0); issue_group(1); issue_group(2);
+    // barrier 0: group 0 has landed (64 DMAs at most were issued after its last one; the counter holds 63: one more is awaited)
+    asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    if (live < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory"); // (fewer DMAs per group: the count above is for four waves)
+    __builtin_amdgcn_s_barrier();
+    for (int r = 0; r + 1 < ngroups; ++r) {
+        if (r + 3 < ngroups) issue_group(r + 3);
+        // group r + 1 must have landed before barrier r + 1
+        if (r + 3 < ngroups && live == 4) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// compute side of the loader-wave variant: no loads, one barrier per group
+template <int NS>
+__device__ __forceinline__ void mf_loop_fed(MfState<NS> &st, const MfConst &k, MfOut &oc, MfFront &fr, unsigned lds_addr, int nper, int WP, int p, int comp, int q)
+{
+    constexpr int P = mf_period<NS>();
+    static_assert(P == 32, "the ring turns once per period");
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned ring = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr + (unsigned)wv * MF_WAVE_RING));
+    const __attribute__((address_space(3))) char *lrd =
+        (const __attribute__((address_space(3))) char *)(size_t)(ring + 16u * (unsigned)(72 * p + 2 * (p >> 2) + 4 * comp + q));
+    __builtin_amdgcn_s_barrier(); // barrier 0: group 0 has landed
+    uint4_t r = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd);
+    for (int per = 0; per < nper; ++per) {
+        oc.store = per >= WP;
+        mf_static_for<P>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int i1 = (i + 1) % P;
+            if constexpr (i1 % 8 == 0) {
+                // the last step of a group: its data is in `r`; behind the barrier the next group has landed and the loader may
+                // overwrite this one.  (The very last barrier of the launch has no partner: skipped.)
+                if (i1 != 0 || per + 1 < nper) __builtin_amdgcn_s_barrier();
+            }
+            const uint4_t rn = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd + (i1 / 8) * MF_GROUP_BYTES + 128 * (i1 % 8));
+            mf_front<NS, i>(st, k, fr, r);
+            mf_stage<NS, 0, i>(st, k, oc, comp);
+            r = rn;
+        });
+    }
 }
 
 template <int NS>
@@ -384,7 +510,7 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no DMA may outlive the workgroup's LDS allocation
 }
 
-template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, unsigned lds_addr)
+template <int NS, bool DMA = true> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, unsigned lds_addr)
 {
     constexpr int L = NS;
     constexpr int P = mf_period<NS>();  // first-stage steps per period of the unrolled schedule
@@ -452,8 +578,12 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
     fr.sel_lo = comp ? 0x05040100u : 0x01000504u; fr.sel_hi = comp ? 0x07060302u : 0x03020706u;
     fr.ev_lo = 0u; fr.ev_hi = 0u;
 #if MF_DMA
-    if constexpr (mf_dma_applies(NS)) {
+    if constexpr (DMA && mf_dma_applies(NS)) {
+#if MF_LOADER
+        mf_loop_fed<NS>(st, k, oc, fr, lds_addr, nper, WP, p, comp, q);
+#else
         mf_loop_dma<NS>(a, st, k, oc, fr, lds_addr, wbase, S, nper, WP, lane, p, comp, q);
+#endif
         return;
     }
 #endif
@@ -475,7 +605,7 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
     // operations exactly only inside a basic block, drains the ring with a vmcnt(0) at the top of every period: same
     // launch time, 0.255 ms both ways, and the register allocator may copy an asm load's destination before the wait.)
 #pragma unroll
-    for (int d = 0; d < D; ++d) ld[d] = *reinterpret_cast<const uint4_t *>(src + MF_LDSTRIDE * d);
+    for (int d = 0; d < D; ++d) ld[d] = SDRHIP_STREAM_LOAD(reinterpret_cast<const uint4_t *>(src + MF_LDSTRIDE * d));
 
     for (int per = 0; per < nper; ++per) {
         oc.store = per >= WP;
@@ -486,7 +616,7 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
 #if MF_ABL & 512 // timing experiment (wrong data): no loads in the loop, the arithmetic runs on stale registers
             asm volatile("" : "+v"(ld[slot]));
 #else
-            ld[slot] = *reinterpret_cast<const uint4_t *>(src + MF_LDSTRIDE * (i + D));
+            ld[slot] = SDRHIP_STREAM_LOAD(reinterpret_cast<const uint4_t *>(src + MF_LDSTRIDE * (i + D)));
 #endif
 #if MF_ABL & 16
             asm volatile("" : "+v"(st.O[0][0]), "+v"(st.O[0][1]) : "v"(r));
@@ -502,7 +632,10 @@ template <int NS> __device__ __forceinline__ void mf_wave(const DecimArgs &a, in
 
 // grid.x = the matrix-core workgroups (four waves = four groups of 8 spans each), then nstreams * mf_npieces VALU
 // workgroups (head + tail pieces of every stream)
-template <int L, bool PACK16> __global__ __launch_bounds__(NT, mf_dma_applies(L) ? 1 : MF_WAVES) void decim_mfma_kernel(DecimArgs a)
+__host__ __device__ constexpr bool mf_loader_applies(int ns) { return MF_LOADER && mf_dma_applies(ns); }
+__host__ __device__ constexpr int mf_block_threads(int ns) { return mf_loader_applies(ns) ? MF_NT5 : NT; }
+
+template <int L, bool PACK16> __global__ __launch_bounds__(mf_block_threads(L), mf_dma_applies(L) ? 1 : MF_WAVES) void decim_mfma_kernel(DecimArgs a)
 {
     // the VALU pieces' stage buffers, or (matrix-core workgroups of the long cascades) the four waves' LDS-DMA rings
     constexpr int LDSDW = mf_dma_applies(L) && 4 * MF_WAVE_RING / 4 > DecimLds<L, 2, PACK16>::dwords ? 4 * MF_WAVE_RING / 4 : DecimLds<L, 2, PACK16>::dwords;
@@ -512,6 +645,16 @@ template <int L, bool PACK16> __global__ __launch_bounds__(NT, mf_dma_applies(L)
     // that got two of them while the short VALU pieces held slots elsewhere doubled the time of the whole launch.
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
     const int bx = blockIdx.x;
+    if constexpr (mf_loader_applies(L)) {
+        if (threadIdx.x >= NT) { // the fifth wave: loader of a matrix-core workgroup, nothing to do in a VALU piece
+            if (bx < nmf) {
+                constexpr size_t W = (size_t)64 << L;
+                const int nper = (int)((W + a.mf_span) / 32) / mf_period<L>();
+                mf_loader(a, bx, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds, W, 4 * nper);
+            }
+            return;
+        }
+    }
     if (bx >= nmf) {
         const int lx = bx - nmf;
         const int stream = lx / a.mf_npieces, piece = lx - stream * a.mf_npieces;
@@ -530,11 +673,91 @@ template <int L, bool PACK16> __global__ __launch_bounds__(NT, mf_dma_applies(L)
     mf_wave<L>(a, gw, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds);
 }
 
+// ---- fused Rx launch: the decimator of THIS call and the CM256 encoder of the frames the PREVIOUS call completed, in one grid.
+// The matrix-core waves run one per SIMD and leave ~40 % of their SIMD's issue slots empty (memory waits, dependent issue);
+// a kernel boundary cannot fill them, co-resident encoder workgroups can: first the decimator's workgroups (as in
+// decim_mfma_kernel, register ring: its 34 KB of static LDS leave room for three encoder workgroups per CU), then one
+// encoder workgroup per (frame, half block).  No dependency between the two roles inside the launch (sdrhip_pipes.cpp).
+#include "gf_encode128_body.h"
+// Roles are claimed at run time, not by blockIdx: the decimator's workgroups must sit ONE per CU (a launch lasts as long as
+// its fullest CU), but every workgroup of a kernel has the same resource footprint, and with 2 000 encoder workgroups in the
+// grid the dispatcher packs the first 248 workgroups four to a CU (measured: 1.18 ms instead of 0.26).  So a workgroup first
+// asks whether it is the FIRST of this launch on its CU (atomicMax of the launch's tag on a per-CU word, key from HW_ID /
+// XCC_ID): the first ones take the matrix-core units, all others the VALU pieces and the encoder units (leftovers of any
+// kind go to whoever comes last: every unit is run exactly once, whatever the placement).
+#ifndef MF_FUSED_WPE
+#define MF_FUSED_WPE 3
+#endif
+struct FusedRoles {
+    unsigned *tab;  // [4096] per-CU tags + [2][4] unit counters (set tag & 1 is this launch's, the other one is cleared for the next)
+    unsigned tag;   // increases with every launch of the context
+};
+
+template <int L, bool PACK16> __global__ __launch_bounds__(NT, MF_FUSED_WPE) void rx_fused_kernel(DecimArgs a, Enc128Args e, FusedRoles fr)
+{
+    constexpr int LDSDW = ENC128_LDS_BYTES / 4 > DecimLds<L, 2, PACK16>::dwords ? ENC128_LDS_BYTES / 4 : DecimLds<L, 2, PACK16>::dwords;
+    __shared__ __attribute__((aligned(16))) int lds[LDSDW];
+    __shared__ int s_unit;
+    const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
+    const int npiece = a.nstreams * a.mf_npieces;
+    const int nenc = 2 * e.nlist;
+    if (threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned key = ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);
+        unsigned *cnt = fr.tab + 4096 + 4 * (fr.tag & 1u);
+        if (blockIdx.x == 0) { unsigned *nxt = fr.tab + 4096 + 4 * ((fr.tag + 1u) & 1u); nxt[0] = 0u; nxt[1] = 0u; nxt[2] = 0u; }
+        const bool first = atomicMax(fr.tab + key, fr.tag) < fr.tag;
+        int unit = -1;
+        if (first) { const unsigned u = atomicAdd(cnt + 0, 1u); if (u < (unsigned)nmf) unit = (int)u; }
+        if (unit < 0) { const unsigned u = atomicAdd(cnt + 1, 1u); if (u < (unsigned)npiece) unit = nmf + (int)u; }
+        if (unit < 0) { const unsigned u = atomicAdd(cnt + 2, 1u); if (u < (unsigned)nenc) unit = nmf + npiece + (int)u; }
+        if (unit < 0) { const unsigned u = atomicAdd(cnt + 0, 1u); if (u < (unsigned)nmf) unit = (int)u; }
+        s_unit = unit;
+    }
+    __syncthreads();
+    const int bx = s_unit;
+    if (bx < 0) return;
+    const int ndec = nmf + npiece;
+    if (bx >= ndec) {
+        gf_encode128_wg(e, bx - ndec, reinterpret_cast<unsigned char *>(lds));
+        return;
+    }
+    if (bx >= nmf) {
+        const int lx = bx - nmf;
+        const int stream = lx / a.mf_npieces, piece = lx - stream * a.mf_npieces;
+        if (piece == 0) {
+            decim_piece<L, 2, PACK16>(a, lds, stream, 0, a.mf_head, true, false, piece, a.mf_npieces);
+        } else {
+            const size_t s0 = a.mf_tail_start + (size_t)(piece - 1) * a.mf_tail_seg;
+            size_t s1 = s0 + a.mf_tail_seg;
+            if (s1 > a.n_used || piece == a.mf_npieces - 1) s1 = a.n_used;
+            decim_piece<L, 2, PACK16>(a, lds, stream, s0, s1, false, piece == a.mf_npieces - 1, piece, a.mf_npieces);
+        }
+        return;
+    }
+    const int gw = __builtin_amdgcn_readfirstlane(bx * 4 + (int)(threadIdx.x >> 6));
+    if (gw >= a.nstreams * a.mf_wps) return;
+    mf_wave<L, false>(a, gw, 0u);
+}
+
+template <int L> hipError_t launch_fused(bool pack16, const DecimArgs &a, const Enc128Args &e, unsigned *roles, unsigned tag, hipStream_t stream)
+{
+    const int ndec = (a.nstreams * a.mf_wps + 3) / 4 + a.nstreams * a.mf_npieces;
+    const dim3 grid(ndec + 2 * e.nlist), block(NT);
+    FusedRoles fr;
+    fr.tab = roles; fr.tag = tag;
+    if (pack16) hipLaunchKernelGGL((rx_fused_kernel<L, true>), grid, block, 0, stream, a, e, fr);
+    else hipLaunchKernelGGL((rx_fused_kernel<L, false>), grid, block, 0, stream, a, e, fr);
+    return hipGetLastError();
+}
+
 template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream_t stream)
 {
     const int nleg = a.nstreams * a.mf_npieces;
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
-    const dim3 grid(nleg + nmf), block(NT);
+    const dim3 grid(nleg + nmf), block(mf_block_threads(L));
     if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((decim_mfma_kernel<L, false>), grid, block, 0, stream, a);
     return hipGetLastError();
@@ -611,6 +834,16 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
     a->mf_tail_seg = seg;
     a->mf_npieces = 1 + (int)ntail;
     return true;
+}
+
+hipError_t launch_rx_fused(int log2decim, bool pack16, const DecimArgs &a, const Enc128Args &e, unsigned *roles, unsigned tag, hipStream_t stream)
+{
+    switch (log2decim) {
+    case 2: return launch_fused<2>(pack16, a, e, roles, tag, stream);
+    case 3: return launch_fused<3>(pack16, a, e, roles, tag, stream);
+    case 4: return launch_fused<4>(pack16, a, e, roles, tag, stream);
+    }
+    return hipErrorInvalidValue; // (decimate32 / 64: 180-220 VGPRs, no room for encoder waves beside them)
 }
 
 hipError_t launch_decimate_mfma(int log2decim, bool pack16, const DecimArgs &a, hipStream_t stream)

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void frame_pack_kernel(FrameArgs a)
         const uint64_t f = g / 16129u;
         const unsigned w = (unsigned)(g - f * 16129u);
         const unsigned b = w / 127u, i = w - b * 127u;
-        dst[(size_t)f * fdw + (size_t)(1u + b) * 128u + 1u + i] = src[k];
+        dst[(size_t)f * fdw + (size_t)(1u + b) * 128u + 1u + i] = SDRHIP_STREAM_LOAD(src + k);
     }
     // meta block + super block headers of the frames this call starts: frame fi by workgroup fi mod gridDim.x
     if (threadIdx.x < 128) {

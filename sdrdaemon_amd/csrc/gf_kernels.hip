@@ -21,13 +21,12 @@
 namespace sdrhip {
 namespace {
 
-constexpr int GF_NT = 256;
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+#include "gf_encode128_body.h"
 // rows accumulated per wave: RB = 4, 6 or 8, a workgroup (4 waves) = 4 x RB rows of the same frames.  The
 // launch picks the smallest tile that covers the matrix in one workgroup row (24 erasures -> RB = 6): the
 // column slabs are then read and split into selectors once instead of once per 16 rows.
 static_assert(GF_FRAMES_PER_GROUP == 2, "lane mapping below assumes one frame per half-wave");
-
-typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 
 struct Sel { unsigned a, b, c; };
 
@@ -144,181 +143,10 @@ template <int RB> __global__ __launch_bounds__(GF_NT) void gf_apply_kernel(GfArg
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Structured encoder for OriginalCount = 128 (the only geometry sdrdaemon uses, UDPSinkFEC.h:57).
-//
-// The Cauchy element (y_j ^ x_0) / (x_i ^ y_j) with x_0 = 128, x_i = 128 + r, y_j = j is
-//     M[r][j] = (128 ^ j) / (128 ^ (r ^ j)) = 1 ^ r * G[r ^ j],      G[t] = 1 / (128 ^ t)
-// (because (128 ^ j) ^ (128 ^ (r ^ j)) = r), hence
-//     recovery_r = P ^ r * (G (*) x)[r],   P = XOR of the 128 originals,
-// where (*) is an XOR-convolution over the block index: (G (*) x)[r] = XOR_j G[r ^ j] x_j.  Splitting
-// j = 16 cb + jl and r = 16 rt + rl turns it into 16-point dyadic convolutions with the kernel blocks
-// G_b[u] = G[16 b + u], b = rt ^ cb, and over a field of characteristic 2 those obey a Karatsuba rule
-//     y_lo = g_lo(*)z_lo ^ g_hi(*)z_hi,   y_hi = y_lo ^ (g_lo ^ g_hi)(*)(z_lo ^ z_hi)
-// (3 half-size products instead of 4).  Four levels: 81 constant multiplications + 195 XORs per
-// 16 x 16 block instead of 256 multiplications.  The 81 leaf constants of each of the 8 blocks G_b come
-// from the host (gf256.cpp, cm256_karatsuba_leaf_tables) in depth-first order as ready-made 32-byte
-// multiplier tables and sit in LDS as {Ta, Tb} (16 B) + {Tc} (4 B) arrays: immediate offsets, no
-// dependent loads.
-// A lane owns one 4-byte column of a frame; a workgroup = one (frame, half block) = 64 columns; its four
-// waves take two column blocks each, apply them to BOTH 16-row tiles of a row pair in one walk of the
-// tree (acc_conv2), XOR their partial sums into LDS (ds_xor), then each wave finishes 8 of the 32 rows:
-// recovery_r = P ^ r * c_r, and writes their {frameIndex, 128 + r, 0} headers.
-__device__ __forceinline__ unsigned kmul(unsigned zval, const uint4_t &t, unsigned tc)
-{
-    const unsigned sa = zval & 0x07070707u, sb = (zval >> 3) & 0x07070707u, sc = (zval >> 6) & 0x03030303u;
-    return __builtin_amdgcn_perm(t.y, t.x, sa) ^ __builtin_amdgcn_perm(t.w, t.z, sb) ^ __builtin_amdgcn_perm(0u, tc, sc);
-}
-
-__device__ __forceinline__ unsigned lds_addr(const void *p)
-{
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; // generic -> LDS byte address
-}
-
-constexpr int KN = 16;                                                                    // points per block
-constexpr int KLEAVES = 81;                                                               // 3^4
-__host__ __device__ constexpr int pow3(int n) { return n <= 1 ? 1 : 3 * pow3(n / 2); }    // leaves of an n-point node
-__host__ __device__ constexpr int sbase(int n) { return KN + (KN - n); }                  // scratch of the level of size n
-
-// ya[YO .. YO+N) ^= ga (*) v[ZO .. ZO+N) and yb[..] ^= gb (*) v[..] in one walk of the Karatsuba tree: the two
-// kernel blocks (the two 16-row tiles of a row pair) see the same z sums, so the tree's XORs on the z side
-// and the three selector words of every leaf are formed once and used twice.  la16 / la4, lb16 / lb4 = LDS
-// byte addresses of the leaf tables of the two blocks.
-template <int N, int ZO, int YO, int LEAF0>
-__device__ __forceinline__ void acc_conv2(unsigned (&v)[2 * KN - 1], unsigned (&ya)[KN], unsigned (&yb)[KN], unsigned la16, unsigned la4,
-                                          unsigned lb16, unsigned lb4)
-{
-    if constexpr (N == 1) {
-        // The 81 table loads of a block have immediate addresses; left to the compiler they are all
-        // hoisted to the top (hundreds of VGPRs of tables) and spilled.  An asm statement that loads one
-        // leaf's tables and waits for them keeps them in program order; the other waves of the SIMD cover
-        // the LDS latency.
-        uint4_t ta, tb;
-        unsigned tca, tcb;
-        unsigned z = v[ZO]; // tied to the statement ("+v") so that its three selector dwords are formed here,
-                            // not when v[ZO] is produced (that alone tripled the live registers)
-        asm volatile("ds_read_b128 %0, %5 offset:%c9\n\tds_read_b32 %1, %6 offset:%c10\n\t"
-                     "ds_read_b128 %2, %7 offset:%c9\n\tds_read_b32 %3, %8 offset:%c10\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(ta), "=&v"(tca), "=&v"(tb), "=&v"(tcb), "+v"(z)
-                     : "v"(la16), "v"(la4), "v"(lb16), "v"(lb4), "i"(LEAF0 * 16), "i"(LEAF0 * 4)
-                     : "memory");
-        const unsigned sa = z & 0x07070707u, sb = (z >> 3) & 0x07070707u, sc = (z >> 6) & 0x03030303u;
-        ya[YO] ^= __builtin_amdgcn_perm(ta.y, ta.x, sa) ^ __builtin_amdgcn_perm(ta.w, ta.z, sb) ^ __builtin_amdgcn_perm(0u, tca, sc);
-        yb[YO] ^= __builtin_amdgcn_perm(tb.y, tb.x, sa) ^ __builtin_amdgcn_perm(tb.w, tb.z, sb) ^ __builtin_amdgcn_perm(0u, tcb, sc);
-        asm volatile("" : "+v"(ya[YO]), "+v"(yb[YO])); // accumulate now: the compiler otherwise parks the six products of many leaves
-    } else {
-        constexpr int H = N / 2, L3 = pow3(H);
-#pragma unroll
-        for (int i = 0; i < H; ++i) { ya[YO + H + i] ^= ya[YO + i]; yb[YO + H + i] ^= yb[YO + i]; }
-        acc_conv2<H, ZO, YO, LEAF0>(v, ya, yb, la16, la4, lb16, lb4);
-        acc_conv2<H, ZO + H, YO, LEAF0 + L3>(v, ya, yb, la16, la4, lb16, lb4);
-#pragma unroll
-        for (int i = 0; i < H; ++i) v[sbase(N) + i] = v[ZO + i] ^ v[ZO + H + i];
-        acc_conv2<H, sbase(N), YO + H, LEAF0 + 2 * L3>(v, ya, yb, la16, la4, lb16, lb4);
-#pragma unroll
-        for (int i = 0; i < H; ++i) { ya[YO + H + i] ^= ya[YO + i]; yb[YO + H + i] ^= yb[YO + i]; }
-    }
-}
-
 __global__ __launch_bounds__(GF_NT, 4) void gf_encode128_kernel(Enc128Args a) // 105 VGPRs: 4 waves per SIMD
 {
-    __shared__ __attribute__((aligned(16))) uint4_t lt16[8 * KLEAVES];  // {Ta, Tb} of the leaves of G_0..G_7
-    __shared__ unsigned lt4[8 * KLEAVES];                                // {Tc}
-    __shared__ __attribute__((aligned(16))) uint4_t rt16[128];          // tables of the row constants r < 128
-    __shared__ unsigned rt4[128];
-    __shared__ unsigned ysum[33][64];                                    // reduced convolution (32 rows) + parity (row 32)
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 8 * KLEAVES; i += GF_NT) {
-        const unsigned *src = reinterpret_cast<const unsigned *>(a.leaf_tables) + (size_t)i * 8;
-        lt16[i] = (uint4_t){src[0], src[1], src[2], src[3]};
-        lt4[i] = src[4];
-    }
-    if (tid < 128) {
-        const unsigned *src = reinterpret_cast<const unsigned *>(a.tab) + (size_t)tid * 8;
-        rt16[tid] = (uint4_t){src[0], src[1], src[2], src[3]};
-        rt4[tid] = src[4];
-    }
-    for (int i = tid; i < 33 * 64; i += GF_NT) (&ysum[0][0])[i] = 0;
-    __syncthreads();
-
-    const int w = tid >> 6, lane = tid & 63;  // wave w owns column blocks 2w, 2w + 1
-    const int fi = blockIdx.x >> 1;
-    const int fr = a.frame_list ? a.frame_list[fi] : fi;
-    const int col = (blockIdx.x & 1) * 64 + lane;
-    const bool live = fr >= 0 && fr < a.nframes && col < 127;
-    const size_t frc = live ? (size_t)fr : 0;
-    const unsigned *src = reinterpret_cast<const unsigned *>(a.in + frc * a.in_frame_bytes) + 1 + (live ? col : 0);
-    unsigned *dst = reinterpret_cast<unsigned *>(a.out + frc * a.out_frame_bytes) + 1 + (live ? col : 0);
-    const unsigned hdr0 = (live && col == 0) ? src[-1] : 0u;
-    // fused framing: blocks 1..127 of this frame come straight from the decimated stream (127 samples each)
-    bool fused = false;
-    const unsigned *bsrc = src; // block b at bsrc[b * bstride]
-    int bstride = 128;
-    if (a.lin && live) {
-        const int s = fr / a.lin_cap, f = fr - s * a.lin_cap;
-        if (f >= a.lin_first) {
-            fused = true;
-            bsrc = a.lin + (size_t)s * a.lin_stride + ((size_t)f * 16129u - (size_t)a.lin_pending) + col - 127;
-            bstride = 127;
-        }
-    }
-    unsigned *fdst = const_cast<unsigned *>(src);
-
-    const int npairs = (a.rows + 31) / 32; // pairs of 16-row tiles
-#pragma unroll 1
-    for (int tp = 0; tp < npairs; ++tp) {
-        unsigned y0[KN], y1[KN];
-#pragma unroll
-        for (int i = 0; i < KN; ++i) { y0[i] = 0; y1[i] = 0; }
-        unsigned p = 0;
-#pragma unroll 1
-        for (int q = 0; q < 2; ++q) {
-            const int cb = 2 * w + q;
-            unsigned v[2 * KN - 1];
-            if (live) {
-                // (block 0 = the meta block is never in the stream)
-                v[0] = (fused && cb == 0) ? src[0] : bsrc[(size_t)(KN * cb) * bstride];
-#pragma unroll
-                for (int i = 1; i < KN; ++i) v[i] = bsrc[(size_t)(KN * cb + i) * bstride];
-                if (fused && tp == 0) {
-#pragma unroll
-                    for (int i = 0; i < KN; ++i) fdst[(size_t)(KN * cb + i) * 128] = v[i];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < KN; ++i) v[i] = 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < KN; ++i) p ^= v[i];
-            const int b0 = (2 * tp) ^ cb, b1 = (2 * tp + 1) ^ cb;
-            acc_conv2<KN, 0, 0, 0>(v, y0, y1, lds_addr(lt16 + b0 * KLEAVES), lds_addr(lt4 + b0 * KLEAVES),
-                                   lds_addr(lt16 + b1 * KLEAVES), lds_addr(lt4 + b1 * KLEAVES));
-        }
-        if (tp == 0) __hip_atomic_fetch_xor(&ysum[32][lane], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int i = 0; i < KN; ++i) {
-            __hip_atomic_fetch_xor(&ysum[i][lane], y0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_xor(&ysum[KN + i][lane], y1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        __syncthreads();
-        // rows 8 w .. 8 w + 7 of the 32-row pair: recovery_r = P ^ r * c_r
-        const unsigned P = ysum[32][lane];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int rl = 8 * w + q, r = 32 * tp + rl;
-            if (r < a.rows && live) {
-                dst[(size_t)r * 128] = P ^ kmul(ysum[rl][lane], rt16[r], rt4[r]);
-                // header {frameIndex (of the frame's block 0), 128 + r, filler 0}, UDPSinkFEC.cpp:239-243
-                if (col == 0) dst[(size_t)r * 128 - 1] = (hdr0 & 0xffffu) | ((unsigned)(128 + r) << 16);
-            }
-        }
-        if (tp + 1 < npairs) {
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 8; ++q) ysum[8 * w + q][lane] = 0;
-            __syncthreads();
-        }
-    }
+    __shared__ __attribute__((aligned(16))) unsigned char ldsraw[ENC128_LDS_BYTES];
+    gf_encode128_wg(a, (int)blockIdx.x, ldsraw);
 }
 
 // scatter copy of 508-byte blocks: dst[f][map[f][p]] = src[f][p] for map >= 0

@@ -200,7 +200,7 @@ template <int L> __device__ __forceinline__ void interp_segment(const InterpArgs
 #pragma unroll
         for (int n = 0; n < CI / NT; ++n) {
             const int m = tid + n * NT;
-            ldv[n] = (m < cnt) ? in[p + m] : 0u;
+            ldv[n] = (m < cnt) ? SDRHIP_STREAM_LOAD(in + p + m) : 0u;
         }
     };
     int cnt = warm ? WARM : (int)((seg_end - pos) < (size_t)CI ? (seg_end - pos) : (size_t)CI);

@@ -143,6 +143,8 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
             hipMemcpy(c->gf_explog, el, sizeof(el), hipMemcpyHostToDevice) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "upload GF(256) exp/log tables"); }
     }
     if (hipMalloc(reinterpret_cast<void **>(&c->decim_dump), 4096) != hipSuccess) { c->decim_dump = nullptr; ctx_free(c); return fail(SDRHIP_ENOMEM, "hipMalloc decimator scratch"); }
+    if (hipMalloc(reinterpret_cast<void **>(&c->fused_roles), SDRHIP_FUSED_ROLE_WORDS * 4) != hipSuccess ||
+        hipMemset(c->fused_roles, 0, SDRHIP_FUSED_ROLE_WORDS * 4) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "hipMalloc role table"); }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { ctx_free(c); return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
     *out = c;
     return SDRHIP_OK;
@@ -185,7 +187,7 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
     } else if (k == "mfma_span" && isnum) c->opt.mfma_span = (size_t)num;
     else if (k == "mfma_min" && isnum) c->opt.mfma_min = (size_t)num;
     else if (k == "interp_span" && isnum) c->opt.interp_span = (size_t)num;
-    else if (k == "rx_fused" && isnum) c->opt.rx_fused = num ? 1 : 0;
+    else if (k == "rx_fused" && isnum) c->opt.rx_fused = (int)num;
     else return fail(SDRHIP_EINVAL, "ctx_set_option: unknown key or malformed value: %s=%s", key, value);
     return SDRHIP_OK;
 }
@@ -200,6 +202,7 @@ static void sdrhip::ctx_free(sdrhip_ctx *c)
     if (c->enc_matrix) (void)hipFree(c->enc_matrix);
     if (c->enc_leaves) (void)hipFree(c->enc_leaves);
     if (c->decim_dump) (void)hipFree(c->decim_dump);
+    if (c->fused_roles) (void)hipFree(c->fused_roles);
     if (c->gf_explog) (void)hipFree(c->gf_explog);
     c->dec_plan.release();
     c->pin.release();
@@ -335,8 +338,9 @@ namespace sdrhip {
 // device-pointer core shared with the fused Rx pipe; frame_* = 0 for plain output
 int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in,
                     size_t n_in, size_t in_stride, int16_t *out, size_t out_stride, size_t *n_out, int frame_mode,
-                    int frame_blocks, uint64_t frame_sample_base, const RxMeta *meta)
+                    int frame_blocks, uint64_t frame_sample_base, const RxMeta *meta, const Enc128Args *fuse, bool *fused)
 {
+    if (fused) *fused = false;
     sdrhip_ctx *c = d->ctx;
     const unsigned L = (unsigned)log2decim;
     const unsigned ss = *sampleSize;
@@ -391,7 +395,22 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     hipError_t e;
     {
         KTimer kt(c, SDRHIP_K_DECIMATE);
-        e = use_mfma ? launch_decimate_mfma((int)L, pack16, a, c->stream) : launch_decimate((int)L, fcpos, pack16, a, c->stream);
+        if (use_mfma && fuse && L <= 4) { // (decimate32 / 64: 180-220 VGPRs, no room for encoder waves beside them)
+            if (++c->fused_tag == 0xffffffffu) { // (the per-CU words hold the highest tag seen: start over before it wraps)
+                (void)hipMemsetAsync(c->fused_roles, 0, SDRHIP_FUSED_ROLE_WORDS * 4, c->stream);
+                c->fused_tag = 1;
+            }
+            if (c->opt.rx_fused == 2) { // (experiment: the fused kernel without encoder units, the encoder as its own launch)
+                Enc128Args none = *fuse;
+                none.nlist = 0;
+                e = launch_rx_fused((int)L, pack16, a, none, c->fused_roles, c->fused_tag, c->stream);
+                if (e == hipSuccess) e = launch_gf_encode128(*fuse, c->stream);
+            } else
+            e = launch_rx_fused((int)L, pack16, a, *fuse, c->fused_roles, c->fused_tag, c->stream);
+            if (fused) *fused = true;
+        } else {
+            e = use_mfma ? launch_decimate_mfma((int)L, pack16, a, c->stream) : launch_decimate((int)L, fcpos, pack16, a, c->stream);
+        }
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "decimate launch: %s", hipGetErrorString(e));
     d->last.path = use_mfma ? DECIM_PATH_MFMA : DECIM_PATH_VALU;

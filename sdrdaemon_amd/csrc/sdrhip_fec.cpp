@@ -16,6 +16,17 @@ namespace sdrhip {
 // below this many recovery blocks the generic kernel (rows x 128 products) is cheaper than a full
 // 32-row Karatsuba tile (13.7 k lane-ops per column vs 36 k x rows / 32): ENC128_MIN_ROWS, sdrhip_internal.h
 
+int fec_encode128_launch(sdrhip_ctx *c, const Enc128Args &k)
+{
+    hipError_t e;
+    {
+        KTimer kt(c, SDRHIP_K_FEC_ENCODE);
+        e = launch_gf_encode128(k, c->stream);
+    }
+    if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec encode launch: %s", hipGetErrorString(e));
+    return SDRHIP_OK;
+}
+
 int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
                       size_t rec_frame_bytes, const int32_t *frame_list_dev, int ngroups, const EncodeLin *lin)
 {

@@ -67,7 +67,7 @@ inline unsigned decimated_sample_size(unsigned log2decim, unsigned ss)
 // device-pointer cores (no argument validation, no staging)
 int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in, size_t n_in,
                     size_t in_stride, int16_t *out, size_t out_stride, size_t *n_out, int frame_mode, int frame_blocks,
-                    uint64_t frame_sample_base, const RxMeta *meta = nullptr);
+                    uint64_t frame_sample_base, const RxMeta *meta = nullptr, const Enc128Args *fuse = nullptr, bool *fused = nullptr);
 bool decimate_mfma_applies(const sdrhip_decimators *d, int log2decim, int fcpos, size_t n_in);
 int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *in, size_t n_in, size_t in_stride, int16_t *out,
                        size_t out_stride, size_t *n_out);
@@ -85,6 +85,8 @@ struct EncodeLin {
 inline bool fec_encode_fuses_framing(int nb_fec) { return nb_fec >= sdrhip::ENC128_MIN_ROWS; }
 int fec_encode_device(sdrhip_ctx *ctx, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
                       size_t rec_frame_bytes, const int32_t *frame_list_dev = nullptr, int ngroups = 0, const EncodeLin *lin = nullptr);
+// the structured 128-original encoder on prepared arguments (the Rx pipe's deferred encode)
+int fec_encode128_launch(sdrhip_ctx *ctx, const Enc128Args &k);
 // rx on the device, indices on the host; payload_out / block0_out on the device
 int fec_decode_device(sdrhip_ctx *ctx, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
                       uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out);
@@ -128,6 +130,8 @@ struct sdrhip_ctx {
     uint8_t *enc_matrix = nullptr;           // 128 x 128 encode matrix, rows 128..255 (device)
     uint8_t *enc_leaves = nullptr;           // Karatsuba leaf tables of the structured k = 128 encoder (device)
     unsigned *decim_dump = nullptr;          // sink of the matrix-core decimator's warm-up stores (DecimArgs::mf_dump)
+    unsigned *fused_roles = nullptr;         // role table of the fused Rx launch (rx_fused_kernel), fused_tag = its launch counter
+    unsigned fused_tag = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *gf_explog = nullptr;             // exp[512] + log[256] (uint16) of GF(256) for the decode planner (device)
     sdrhip::DevBuf dec_plan;                  // per-frame decode plans of the current batch (DecodeBuffers)

@@ -4,6 +4,17 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// loads of data that is streamed through once (IQ input, frames): non-temporal.  tools/dma_probe.hip on MI355X: 7.1 TB/s with
+// `nt` against 6.2 TB/s with the default cache policy, register loads and LDS-DMA alike (stores: no difference).
+#ifndef SDRHIP_NT
+#define SDRHIP_NT 1
+#endif
+#if SDRHIP_NT
+#define SDRHIP_STREAM_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define SDRHIP_STREAM_LOAD(ptr) (*(ptr))
+#endif
+
 namespace sdrhip {
 
 // Per-stream half-band decimator state: for each of the six filter instances
@@ -95,6 +106,11 @@ void plan_decimate(int log2decim, int fcpos, size_t n_used, int nstreams, int *n
 // mode unsupported); span_override != 0 forces the span length (tests)
 bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, size_t span_override, int n_cu, DecimArgs *a);
 hipError_t launch_decimate_mfma(int log2decim, bool pack16, const DecimArgs &a, hipStream_t stream);
+struct Enc128Args;
+// the same decimator launch (register-ring variant) with encoder workgroups for `e` behind it in the grid (fused Rx step)
+// roles: SDRHIP_FUSED_ROLE_WORDS zero-initialised device words owned by the context, tag: 1, 2, 3 ... per launch on them
+constexpr int SDRHIP_FUSED_ROLE_WORDS = 4096 + 8;
+hipError_t launch_rx_fused(int log2decim, bool pack16, const DecimArgs &a, const Enc128Args &e, unsigned *roles, unsigned tag, hipStream_t stream);
 
 // filter-less paths: log2decim 0 (decimate1) and inf/sup 2, 4 (Decimators.cpp:22-91,127-170)
 hipError_t launch_decimate_simple(int log2decim, int fcpos, const int16_t *in, size_t in_stride, int16_t *out,
@@ -188,6 +204,8 @@ struct Enc128Args {
     int nframes;                    // frames addressable through in/out
     const int32_t *frame_list;      // optional list of frame indices (-1 = skip), nlist entries; NULL = 0..nlist-1
     int nlist;
+    int gen_done, gen_cap;          // gen_done > 0: entry i of the list IS (i / gen_done) * gen_cap + i % gen_done (the Rx pipe's
+                                    // frames: `gen_done` finished slots of each stream, streams gen_cap slots apart), no array
     // Rx pipe behind a stream-order decimator: the payload of super blocks 1..127 of frame slot f >= lin_first of stream s
     // (frame index s * lin_cap + f) is taken from lin[s][f * 16129 - lin_pending ...] instead of the frame area, and
     // written into the frame area on the way (UDPSinkFEC::write's copy, UDPSinkFEC.cpp:134-155, fused into the encoder);

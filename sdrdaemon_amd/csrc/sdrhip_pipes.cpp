@@ -138,12 +138,27 @@ struct sdrhip_rx {
     uint64_t pending_samples; // decimated samples sitting in that slot (the partial frame)
     bool frame_open;          // it has its meta block (a frame was started)
     uint16_t frame_count;     // its m_frameCount
-    size_t view_slot = 0;     // finished frames of the last call: slots view_slot .. view_slot + view_frames
+    // what sdrhip_rx_frames_view shows: the frames the last call DELIVERED
+    const uint8_t *view_base = nullptr; // slot 0 of the delivered window of stream 0
+    size_t view_stride = 0;             // bytes between streams
     size_t view_frames = 0;
-    DevBuf lin;               // stream-order decimator output of a call that is framed by K2
-    DevBuf flist;             // frame list of the encode launch (device), relative to the window
+    DevBuf lin[2];            // stream-order decimator output of a call that is framed by K2 (two: pipelined mode)
+    int lin_sel = 0;
+    DevBuf flist;             // frame list of the generic encode launch (device), relative to the window
     std::vector<int32_t> flist_host;
     size_t flist_done = 0, flist_cap = 0;
+    // ---- pipelined mode (sdrhip_rx_set_pipelined): a call delivers the frames the PREVIOUS call completed; their
+    // recovery blocks are computed by encoder workgroups inside this call's decimator launch (rx_fused_kernel)
+    int pipelined = 0;
+    struct Late {
+        bool have = false;          // frames completed by the previous call wait for delivery
+        bool encode = false;        // ... and still have to be encoded (k)
+        Enc128Args k;
+        const uint8_t *base = nullptr;
+        size_t stride = 0, frames = 0, frame_bytes = 0;
+        size_t slot0 = 0;           // window position inside `work` (overlap check of the sliding window), SIZE_MAX = other area
+    } late;
+    DevBuf old_work;          // the previous frame area after a re-allocation, kept while `late` points into it
 };
 
 static int rx_check_config(const sdrhip_rx_config *cfg);
@@ -174,6 +189,23 @@ static int rx_check_config(const sdrhip_rx_config *cfg)
     return SDRHIP_OK;
 }
 
+// the encode that a pipelined call left for the next launch, now (flush, reconfiguration, a call that cannot fuse it)
+static int rx_settle(sdrhip_rx *rx)
+{
+    if (!rx->late.encode) return SDRHIP_OK;
+    rx->late.encode = false;
+    return fec_encode128_launch(rx->ctx, rx->late.k);
+}
+
+extern "C" int sdrhip_rx_set_pipelined(sdrhip_rx *rx, int on)
+{
+    if (!rx) return fail(SDRHIP_EINVAL, "rx is NULL");
+    sdrhip::CtxLock lock_(rx->ctx);
+    if (!on && rx->late.have) return fail(SDRHIP_EINVAL, "rx_set_pipelined: sdrhip_rx_flush the waiting frames first");
+    rx->pipelined = on ? 1 : 0;
+    return SDRHIP_OK;
+}
+
 extern "C" int sdrhip_rx_reconfigure(sdrhip_rx *rx, const sdrhip_rx_config *cfg)
 {
     if (!rx || !cfg) return fail(SDRHIP_EINVAL, "rx_reconfigure: NULL argument");
@@ -185,6 +217,7 @@ extern "C" int sdrhip_rx_reconfigure(sdrhip_rx *rx, const sdrhip_rx_config *cfg)
     HIP_TRY(hipSetDevice(c->device));
     if (cfg->nb_fec != rx->cfg.nb_fec && rx->cap_frames) {
         // the slots change size: the frame being filled (its 128 original super blocks) moves to slot 0 of a new area
+        if ((rc = rx_settle(rx))) return rc; // (frames waiting for delivery are encoded with the value they completed under)
         const int S = rx->nstreams;
         const size_t old_fb = (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
         const size_t new_fb = (size_t)(SDRHIP_NB_ORIGINAL + cfg->nb_fec) * SDRHIP_UDPSIZE;
@@ -195,11 +228,12 @@ extern "C" int sdrhip_rx_reconfigure(sdrhip_rx *rx, const sdrhip_rx_config *cfg)
                                      rx->cap_frames * old_fb, (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE, S, hipMemcpyDeviceToDevice,
                                      c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream)); // earlier launches may still use the old area
-        rx->work.release();
+        rx->old_work.release();
+        if (rx->late.have) { rx->old_work = rx->work; rx->late.slot0 = SIZE_MAX; } // (still to be delivered from there)
+        else rx->work.release();
         rx->work = fresh;
         rx->base_slot = 0;
-        rx->view_slot = 0;
-        rx->view_frames = 0;
+        if (!rx->late.have) { rx->view_base = nullptr; rx->view_frames = 0; }
     }
     rx->cfg = *cfg;
     return SDRHIP_OK;
@@ -210,7 +244,9 @@ extern "C" void sdrhip_rx_destroy(sdrhip_rx *rx)
     if (!rx) return;
     sdrhip_decimators_destroy(rx->dec);
     rx->work.release();
-    rx->lin.release();
+    rx->old_work.release();
+    rx->lin[0].release();
+    rx->lin[1].release();
     rx->flist.release();
     delete rx;
 }
@@ -218,8 +254,8 @@ extern "C" void sdrhip_rx_destroy(sdrhip_rx *rx)
 extern "C" int sdrhip_rx_frames_view(const sdrhip_rx *rx, const uint8_t **base, size_t *stream_stride_bytes, size_t *n_frames)
 {
     if (!rx || !base || !stream_stride_bytes || !n_frames) return fail(SDRHIP_EINVAL, "rx_frames_view: NULL argument");
-    *base = rx->work.as<uint8_t>() + rx->view_slot * (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
-    *stream_stride_bytes = rx->cap_frames * (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
+    *base = rx->view_base;
+    *stream_stride_bytes = rx->view_stride;
     *n_frames = rx->view_frames;
     return SDRHIP_OK;
 }
@@ -233,7 +269,43 @@ extern "C" int sdrhip_rx_last_plan(const sdrhip_rx *rx, sdrhip_decim_plan *out)
 extern "C" size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in)
 {
     if (!rx) return 0;
-    return (size_t)((rx->pending_samples + (n_in >> rx->cfg.log2decim)) / SDRHIP_SAMPLES_PER_FRAME);
+    const size_t now = (size_t)((rx->pending_samples + (n_in >> rx->cfg.log2decim)) / SDRHIP_SAMPLES_PER_FRAME);
+    if (!rx->pipelined) return now;
+    return rx->late.have && rx->late.frames > now ? rx->late.frames : now; // (a pipelined call delivers the previous call's frames)
+}
+
+// delivery of a finished window: optional copy to the caller's buffer, and the zero-copy view
+static int rx_deliver(sdrhip_rx *rx, const uint8_t *base, size_t stride, size_t frames, size_t frame_bytes, uint8_t *frames_out,
+                      size_t frame_stride_bytes, size_t *n_frames, int mem)
+{
+    sdrhip_ctx *c = rx->ctx;
+    const int S = rx->nstreams;
+    if (frames && frames_out) {
+        if (S > 1 && frame_stride_bytes < frames * frame_bytes) return fail(SDRHIP_EINVAL, "rx_process: frame stride too small");
+        HIP_TRY(hipMemcpy2DAsync(frames_out, S > 1 ? frame_stride_bytes : frames * frame_bytes, base, stride, frames * frame_bytes, S,
+                                 mem == SDRHIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
+    } else if (frames && mem != SDRHIP_MEM_DEVICE) {
+        return fail(SDRHIP_EINVAL, "rx_process: NULL frames_out");
+    }
+    rx->view_base = base; rx->view_stride = stride; rx->view_frames = frames;
+    if (n_frames) *n_frames = frames;
+    return SDRHIP_OK;
+}
+
+extern "C" int sdrhip_rx_flush(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames, int mem)
+{
+    if (!rx) return fail(SDRHIP_EINVAL, "rx is NULL");
+    sdrhip::CtxLock lock_(rx->ctx);
+    if (n_frames) *n_frames = 0;
+    if (mem != SDRHIP_MEM_HOST && mem != SDRHIP_MEM_DEVICE) return fail(SDRHIP_EINVAL, "mem must be SDRHIP_MEM_HOST or SDRHIP_MEM_DEVICE");
+    if (!rx->late.have) { rx->view_frames = 0; return SDRHIP_OK; }
+    HIP_TRY(hipSetDevice(rx->ctx->device));
+    int rc;
+    if ((rc = rx_settle(rx))) return rc;
+    if ((rc = rx_deliver(rx, rx->late.base, rx->late.stride, rx->late.frames, rx->late.frame_bytes, frames_out, frame_stride_bytes, n_frames, mem))) return rc;
+    rx->late.have = false;
+    if (mem == SDRHIP_MEM_HOST) HIP_TRY(hipStreamSynchronize(rx->ctx->stream));
+    return SDRHIP_OK;
 }
 
 extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in, size_t in_stride, uint32_t tv_sec, uint32_t tv_usec,
@@ -254,8 +326,10 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     const size_t done = (size_t)(total / SDRHIP_SAMPLES_PER_FRAME);
     const uint64_t rest = total - (uint64_t)done * SDRHIP_SAMPLES_PER_FRAME;
     if (S == 1) in_stride = n_in;
-    if (done && !frames_out && mem != SDRHIP_MEM_DEVICE) return fail(SDRHIP_EINVAL, "rx_process: NULL frames_out");
-    if (frames_out && S > 1 && done && frame_stride_bytes < done * frame_bytes) return fail(SDRHIP_EINVAL, "rx_process: frame stride too small");
+    const size_t deliver_now = rx->pipelined ? (rx->late.have ? rx->late.frames : 0) : done;
+    const size_t deliver_fb = rx->pipelined && rx->late.have ? rx->late.frame_bytes : frame_bytes;
+    if (deliver_now && !frames_out && mem != SDRHIP_MEM_DEVICE) return fail(SDRHIP_EINVAL, "rx_process: NULL frames_out");
+    if (frames_out && S > 1 && deliver_now && frame_stride_bytes < deliver_now * deliver_fb) return fail(SDRHIP_EINVAL, "rx_process: frame stride too small");
 
     const int16_t *din = iq_in;
     size_t dstride = in_stride;
@@ -274,18 +348,26 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     // ---- work area [stream][slot][128 + R][512]: this call fills slots base_slot .. base_slot + done.  The
     // finished frames stay readable in place until the next call (sdrhip_rx_frames_view); the frame still
     // being filled is the first slot of the next call.  At the end of the area the window wraps: the open
-    // frame moves to slot 0 (one strided copy every few calls instead of a save + restore per call).
+    // frame moves to slot 0 (one strided copy every few calls instead of a save + restore per call).  Frames that
+    // wait for delivery (pipelined mode) are never overwritten: a window that would reach them gets a new area.
     const size_t need = done + 1;
+    if (rx->old_work.p && !(rx->late.have && rx->late.slot0 == SIZE_MAX)) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        rx->old_work.release();
+    }
     if (rx->base_slot + need > rx->cap_frames) {
-        if (need > rx->cap_frames) {
+        const bool late_here = rx->late.have && rx->late.slot0 != SIZE_MAX;
+        const bool wrap_hits_late = late_here && need > rx->late.slot0; // the wrapped window [0, need) against [slot0, slot0 + frames)
+        if (need > rx->cap_frames || wrap_hits_late) {
             DevBuf bigger;
-            const size_t ncap = 4 * need;
+            const size_t ncap = need > rx->cap_frames ? 4 * need : rx->cap_frames;
             if ((rc = bigger.reserve((size_t)S * ncap * frame_bytes))) return rc;
             if (rx->frame_open)
                 HIP_TRY(hipMemcpy2DAsync(bigger.p, ncap * frame_bytes, rx->work.as<uint8_t>() + rx->base_slot * frame_bytes,
                                          rx->cap_frames * frame_bytes, frame_bytes, S, hipMemcpyDeviceToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream)); // earlier launches may still use the old area
-            rx->work.release();
+            if (late_here) { rx->old_work.release(); rx->old_work = rx->work; rx->late.slot0 = SIZE_MAX; }
+            else rx->work.release();
             rx->work = bigger;
             rx->cap_frames = ncap;
         } else if (rx->frame_open) {
@@ -327,19 +409,26 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     size_t n_out = 0;
     EncodeLin elin;
     bool use_lin = false;
+    const bool structured = R >= ENC128_MIN_ROWS && frame_bytes % 4 == 0; // gf_encode128_kernel serves this setting
     const bool filterless = L == 0 || (rx->cfg.fcpos != SDRHIP_FC_CEN && L <= 2); // Decimators.cpp:22-91,127-170: no cascade kernel
+    const Enc128Args *fuse = rx->late.encode && c->opt.rx_fused ? &rx->late.k : nullptr;
+    bool fused = false;
     if (filterless || decimate_mfma_applies(rx->dec, L, rx->cfg.fcpos, n_in)) {
         // ---- decimate in stream order, then K2 lays the samples out as super blocks (+ meta blocks and headers)
         const size_t lstride = (n_dec + 3) & ~(size_t)3;
-        if ((rc = rx->lin.reserve((size_t)S * lstride * 4 + 16))) return rc;
-        rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, rx->lin.as<int16_t>(), lstride, &n_out, 0, 0, 0, nullptr);
+        if (rx->pipelined) rx->lin_sel ^= 1; // (the deferred encoder of the previous call still reads the other one)
+        DevBuf &lin = rx->lin[rx->lin_sel];
+        if (lin.cap < (size_t)S * lstride * 4 + 16 && rx->late.encode) { if ((rc = rx_settle(rx))) return rc; fuse = nullptr; HIP_TRY(hipStreamSynchronize(c->stream)); }
+        if ((rc = lin.reserve((size_t)S * lstride * 4 + 16))) return rc;
+        rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, lin.as<int16_t>(), lstride, &n_out, 0, 0, 0, nullptr, fuse, &fused);
         if (rc) return rc;
+        if (fused) rx->late.encode = false;
         // the frames that lie entirely inside this call's samples are laid out by the encoder (fused copy); K2 does
         // the frame that was open when the call began, the one left open at its end, meta blocks and headers
         if (fec_encode_fuses_framing(R)) {
             const size_t first = rx->pending_samples ? 1 : 0;
             if (done > first && frame_bytes % 4 == 0) {
-                elin.lin = rx->lin.as<unsigned>(); elin.stride = lstride; elin.cap = (int)rx->cap_frames;
+                elin.lin = lin.as<unsigned>(); elin.stride = lstride; elin.cap = (int)rx->cap_frames;
                 elin.first = (int)first; elin.pending = (int)rx->pending_samples;
                 use_lin = true;
             }
@@ -350,7 +439,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
             fa.skip_from = (size_t)elin.first * SDRHIP_SAMPLES_PER_FRAME - (size_t)elin.pending;
             fa.skip_to = done * SDRHIP_SAMPLES_PER_FRAME - (size_t)elin.pending;
         }
-        fa.in = rx->lin.as<unsigned>(); fa.out = reinterpret_cast<unsigned *>(work);
+        fa.in = lin.as<unsigned>(); fa.out = reinterpret_cast<unsigned *>(work);
         fa.in_stride = lstride; fa.out_stride = stream_bytes / 4;
         fa.n = n_dec; fa.frame_sample_base = rx->pending_samples; fa.frame_blocks = FB;
         fa.meta_first = meta.first; fa.meta_count = meta.count; fa.meta_frame_count0 = meta.frame_count0;
@@ -364,34 +453,58 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
                              FB, rx->pending_samples, &meta);
         if (rc) return rc;
     }
+    if ((rc = rx_settle(rx))) return rc; // (a waiting encode that this call's launch could not take along)
 
     // ---- FEC over the completed frames of every stream, recovery blocks land behind block 127
+    bool encode_later = false;
+    Enc128Args k;
+    memset(&k, 0, sizeof(k));
     if (done && R > 0) {
-        // one launch for every stream: frame (s, f) is frame s * cap_frames + f of the work area
-        if (rx->flist_done != done || rx->flist_cap != rx->cap_frames) {
-            HIP_TRY(hipStreamSynchronize(c->stream)); // a previous upload may still read flist_host
-            rx->flist_host.clear();
-            for (int s = 0; s < S; ++s)
-                for (size_t f = 0; f < done; ++f) rx->flist_host.push_back((int32_t)(s * rx->cap_frames + f));
-            while (rx->flist_host.size() % GF_FRAMES_PER_GROUP) rx->flist_host.push_back(-1);
-            if ((rc = rx->flist.reserve(rx->flist_host.size() * 4))) return rc;
-            HIP_TRY(hipMemcpyAsync(rx->flist.p, rx->flist_host.data(), rx->flist_host.size() * 4, hipMemcpyHostToDevice, c->stream));
-            rx->flist_done = done; rx->flist_cap = rx->cap_frames;
+        if (structured) {
+            // structured encoder, one workgroup per (frame, half block); frame (s, f) of the window is frame s * cap_frames + f
+            k.in = work; k.out = work + (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE; k.tab = c->gf_tab; k.leaf_tables = c->enc_leaves;
+            k.in_frame_bytes = frame_bytes; k.out_frame_bytes = frame_bytes;
+            k.rows = R; k.nframes = (int)((size_t)S * rx->cap_frames);
+            k.nlist = (int)((size_t)S * done); k.gen_done = (int)done; k.gen_cap = (int)rx->cap_frames;
+            if (use_lin) { k.lin = elin.lin; k.lin_stride = elin.stride; k.lin_cap = elin.cap; k.lin_first = elin.first; k.lin_pending = elin.pending; }
+            if (rx->pipelined) encode_later = true; // rides in the next call's decimator launch (or sdrhip_rx_flush)
+            else if ((rc = fec_encode128_launch(c, k))) return rc;
+        } else {
+            // generic matrix kernel: one launch for every stream, frame list in groups of GF_FRAMES_PER_GROUP
+            if (rx->flist_done != done || rx->flist_cap != rx->cap_frames) {
+                HIP_TRY(hipStreamSynchronize(c->stream)); // a previous upload may still read flist_host
+                rx->flist_host.clear();
+                for (int s = 0; s < S; ++s)
+                    for (size_t f = 0; f < done; ++f) rx->flist_host.push_back((int32_t)(s * rx->cap_frames + f));
+                while (rx->flist_host.size() % GF_FRAMES_PER_GROUP) rx->flist_host.push_back(-1);
+                if ((rc = rx->flist.reserve(rx->flist_host.size() * 4))) return rc;
+                HIP_TRY(hipMemcpyAsync(rx->flist.p, rx->flist_host.data(), rx->flist_host.size() * 4, hipMemcpyHostToDevice, c->stream));
+                rx->flist_done = done; rx->flist_cap = rx->cap_frames;
+            }
+            if ((rc = fec_encode_device(c, work, frame_bytes, (size_t)S * rx->cap_frames, R, work + (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE,
+                                        frame_bytes, rx->flist.as<int32_t>(), (int)(rx->flist_host.size() / GF_FRAMES_PER_GROUP), nullptr)))
+                return rc;
         }
-        if ((rc = fec_encode_device(c, work, frame_bytes, (size_t)S * rx->cap_frames, R, work + (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE,
-                                    frame_bytes, rx->flist.as<int32_t>(), (int)(rx->flist_host.size() / GF_FRAMES_PER_GROUP), use_lin ? &elin : nullptr)))
-            return rc;
     }
-    if (done && frames_out)
-        HIP_TRY(hipMemcpy2DAsync(frames_out, S > 1 ? frame_stride_bytes : done * frame_bytes, work, stream_bytes, done * frame_bytes, S,
-                                 mem == SDRHIP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
-    rx->view_slot = rx->base_slot;
-    rx->view_frames = done;
+    // ---- delivery: this call's frames, or (pipelined) the previous call's, whose encode went out above
+    if (rx->pipelined) {
+        if (rx->late.have) {
+            if ((rc = rx_deliver(rx, rx->late.base, rx->late.stride, rx->late.frames, rx->late.frame_bytes, frames_out, frame_stride_bytes, n_frames, mem))) return rc;
+        } else {
+            rx->view_base = nullptr; rx->view_frames = 0;
+        }
+        rx->late.have = done > 0;
+        rx->late.encode = encode_later;
+        rx->late.k = k;
+        rx->late.base = work; rx->late.stride = stream_bytes; rx->late.frames = done; rx->late.frame_bytes = frame_bytes;
+        rx->late.slot0 = rx->base_slot;
+    } else {
+        if ((rc = rx_deliver(rx, work, stream_bytes, done, frame_bytes, frames_out, frame_stride_bytes, n_frames, mem))) return rc;
+    }
     rx->base_slot += done; // the frame still being filled opens the next call's window
     rx->pending_samples = rest;
     rx->frame_open = rest > 0;
     rx->frame_count = (uint16_t)(rx->frame_count + done);
-    if (n_frames) *n_frames = done;
     if (mem == SDRHIP_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream));
     return SDRHIP_OK;
 }

@@ -438,17 +438,43 @@ class RxPipe:
     """Downsampler -> UDPSinkFEC framing -> CM256 encode for a bank of streams (sdrhip_rx)."""
 
     def __init__(self, ctx, nstreams=1, log2decim=4, fcpos=FC_CEN, hb_variant=HB_EO1, sample_bits=16, nb_fec=32,
-                 center_frequency_khz=435000, sample_rate=625000):
+                 center_frequency_khz=435000, sample_rate=625000, pipelined=False):
+        """pipelined: a process() call returns the frames the PREVIOUS call completed (their recovery blocks are computed inside
+        this call's decimator launch, sdrhip_rx_set_pipelined); flush() / flush_view() return the last call's at the end."""
         self.ctx, self.nstreams, self.nb_fec = ctx, nstreams, nb_fec
         self.cfg = RxConfig(log2decim, fcpos, hb_variant, sample_bits, nb_fec, center_frequency_khz, sample_rate)
         self.h = C.c_void_p()
         self.m_error = ""
         self.m_device_rate = sample_rate << log2decim  # DeviceSource::get_sample_rate(): the sink gets it >> decim
         check(ctx.lib.sdrhip_rx_create(ctx.h, nstreams, C.byref(self.cfg), C.byref(self.h)))
+        self.pipelined = bool(pipelined)
+        if pipelined:
+            check(ctx.lib.sdrhip_rx_set_pipelined(self.h, 1))
 
     def error(self):
         e, self.m_error = self.m_error, ""
         return e
+
+    def _view(self, device):
+        base, stride, cnt = C.c_void_p(0), C.c_size_t(0), C.c_size_t(0)
+        check(self.ctx.lib.sdrhip_rx_frames_view(self.h, C.byref(base), C.byref(stride), C.byref(cnt)))
+        fb = (NB_ORIGINAL + self.nb_fec) * UDPSIZE
+        return _DeviceView(base.value or 0, (self.nstreams, cnt.value, NB_ORIGINAL + self.nb_fec, UDPSIZE), (stride.value, fb, UDPSIZE, 1), device, owner=self)
+
+    def flush_view(self, device="cuda"):
+        """pipelined mode: encode and show (zero copy) the frames the last process() call completed"""
+        nf = C.c_size_t(0)
+        check(self.ctx.lib.sdrhip_rx_flush(self.h, C.c_void_p(0), 0, C.byref(nf), MEM_DEVICE))
+        return self._view(torch.device(device))
+
+    def flush(self):
+        """pipelined mode: -> the frames the last process() call completed, as a host array (S, n, 128 + nb_fec, 512)"""
+        cap = max(self.max_frames(0), 1)
+        fb = (NB_ORIGINAL + self.nb_fec) * UDPSIZE
+        out = np.empty((self.nstreams, cap, NB_ORIGINAL + self.nb_fec, UDPSIZE), np.uint8)
+        nf = C.c_size_t(0)
+        check(self.ctx.lib.sdrhip_rx_flush(self.h, _ptr(out), cap * fb, C.byref(nf), MEM_HOST))
+        return out[:, :nf.value]
 
     def last_plan(self):
         """the decimator launch of the last process() call (sdrhip_rx_last_plan)"""
@@ -524,10 +550,7 @@ class RxPipe:
         nf = C.c_size_t(0)
         check(self.ctx.lib.sdrhip_rx_process(self.h, _ptr(x), n, _stride_samples(x), tv_sec, tv_usec, C.c_void_p(0), 0,
                                              C.byref(nf), MEM_DEVICE))
-        base, stride, cnt = C.c_void_p(0), C.c_size_t(0), C.c_size_t(0)
-        check(self.ctx.lib.sdrhip_rx_frames_view(self.h, C.byref(base), C.byref(stride), C.byref(cnt)))
-        fb = (NB_ORIGINAL + self.nb_fec) * UDPSIZE
-        return _DeviceView(base.value, (S, cnt.value, NB_ORIGINAL + self.nb_fec, UDPSIZE), (stride.value, fb, UDPSIZE, 1), x.device, owner=self)
+        return self._view(x.device)
 
     def close(self):
         if self.h:

@@ -170,3 +170,61 @@ def test_reference_goldens_through_both_kernels(ctx, path):
     finally:
         ctx.set_option("decim_path", "auto")
         ctx.set_option("mfma_span", 0)
+
+
+def test_headline_pipelined_fused_launch(ctx):
+    """bench.py's pipelined step: call N's decimator launch carries the encoder workgroups of call N - 1's frames
+    (rx_fused_kernel).  Two steps over the same bank + flush: step 1 delivers nothing, step 2 delivers step 1's frames =
+    the reference digests; the flushed frames (second step: streams continue, filter history) equal the unpipelined pipe's."""
+    import torch
+
+    x, b = _bank("bank8")
+    m = H["meta"]
+    ref = _rx(ctx, x.shape[0])
+    ref.process_view(x, tv_sec=m["tv_sec"], tv_usec=m["tv_usec"])
+    second = ref.process_view(x, tv_sec=7, tv_usec=9).torch().clone()
+    import sdrdaemon_amd as sd
+
+    rx = sd.RxPipe(ctx, x.shape[0], log2decim=4, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=m["nb_fec"],
+                   center_frequency_khz=m["center_frequency_khz"], sample_rate=m["sample_rate"], pipelined=True)
+    v0 = rx.process_view(x, tv_sec=m["tv_sec"], tv_usec=m["tv_usec"])
+    assert v0.shape[1] == 0
+    v1 = rx.process_view(x, tv_sec=7, tv_usec=9)
+    ctx.synchronize()
+    assert rx.last_plan()["path"] == "mfma"
+    _check_frames(v1, b)
+    v2 = rx.flush_view().torch()
+    ctx.synchronize()
+    assert torch.equal(v2, second)
+    assert rx.flush_view().shape[1] == 0
+
+
+@pytest.mark.parametrize("cfg", [(4, 32, 1), (4, 32, 3), (3, 16, 2), (2, 32, 1), (4, 8, 1), (1, 32, 2), (5, 32, 1)])
+def test_pipelined_equals_unpipelined_ragged(ctx, oracle, cfg):
+    """pipelined mode on ragged host calls (frames straddling calls, calls too short for the matrix cores, the generic encoder
+    at nb_fec = 8, the VALU path at decimate2, decimate32 = no fused launch): same frames, one call later, flush at the end"""
+    import sdrdaemon_amd as sd
+
+    log2, R, S = cfg
+    ctx.set_option("decim_path", "mfma")
+    ctx.set_option("mfma_span", 64 << log2)
+    try:
+        n = (4 * 16129 + 3000) << log2
+        xs = np.stack([signals.noise(n, 50 + s) for s in range(S)])
+        cuts = [0, n // 3 + 64, n // 3 + 64 + (500 << log2), (2 * n // 3) & ~63, n]
+        a = sd.RxPipe(ctx, S, log2decim=log2, nb_fec=R)
+        p = sd.RxPipe(ctx, S, log2decim=log2, nb_fec=R, pipelined=True)
+        exp, got = [], []
+        for i in range(4):
+            seg = xs[:, cuts[i]:cuts[i + 1]]
+            exp.append(a.process(seg, 10 + i, 5 * i))
+            got.append(p.process(seg, 10 + i, 5 * i))
+        got.append(p.flush())
+        assert got[0].shape[1] == 0
+        exp, got = np.concatenate(exp, axis=1), np.concatenate(got, axis=1)
+        assert exp.shape[1] == 4 and np.array_equal(exp, got), cfg
+        # and against the oracle chain for one stream
+        y, ss = oracle.decimators(0).decimate(log2, 2, 16, xs[0])
+    finally:
+        ctx.set_option("decim_path", "auto")
+        ctx.set_option("mfma_span", 0)

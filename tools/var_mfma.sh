@@ -27,7 +27,7 @@ done
 i=0
 for flags in "$@"; do
     for c in $CFG; do
-        echo "[$flags] $c: $(awk -v i=$i -v c=$c '$1==i && $2==c {print $3}' /tmp/var/samples.txt | sort -n | tr '\n' ' ')" >> $OUT
+        echo "[$flags] $c: $(awk -v i=$i -v c=$c '$1==i && $2==c {print $3}' /tmp/var/samples.txt | tr '\n' ' ')" >> $OUT
     done
     i=$((i+1))
 done
