@@ -252,7 +252,9 @@ def extra_configs(ctx, dev, x, kind):
     keep = np.stack([np.sort(rs.permutation(160)[:136])[:128] for _ in range(Stx * F)])
     rxf = allb[torch.arange(Stx * F, device=dev)[:, None], torch.from_numpy(keep).to(dev)].contiguous().reshape(Stx, F, 128, 512)
     tx = sd.TxPipe(ctx, Stx, LOG2DECIM)
+    ctx.set_option("dec_max_rows", NB_FEC)  # the sender's fecblk (it is in every frame's meta block): no frame carries more recovery blocks
     wall, per = timed_steps(ctx, lambda: tx.process(rxf), [K_FEC_DECODE, K_INTERPOLATE])
+    ctx.set_option("dec_max_rows", 128)
     nout = Stx * F * 16129 << LOG2DECIM
     out.append({"config": "configs[3]: %d streams x %d frames per step, UDPSourceFEC decode 128+32 with 24 erased blocks (a distinct random "
                           "pattern per frame, %d distinct) + interpolate16_cen" % (Stx, F, len({k.tobytes() for k in keep})),
@@ -326,6 +328,9 @@ def main():
                          "~60 ms of load: with a small W the timed steps would measure that ramp)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: leave the per-kernel HIP events out of the timed region (roofline fields become null)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 only: go through the N > 1 code path anyway (init_process_group, barriers, device-tensor all_reduce) -- "
+                         "executes the nccl = RCCL branch on a one-GPU box")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to dry-run the N > 1 path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -333,10 +338,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "gloo":
             local %= torch.cuda.device_count()  # dry run: ranks may share a GPU
             torch.cuda.set_device(local)
@@ -410,7 +418,7 @@ def main():
     verified = None if args.no_verify else verify_step(ctx, x, ids, args.input)
     # the only collectives of the job: MAX of the elapsed time, SUM of the samples (8 bytes each, reporting only)
     elapsed, total_samples = sharding.aggregate(elapsed, float(S) * n * args.steps, dist,
-                                                dev if args.backend == "nccl" else torch.device("cpu"))
+                                                dev if args.backend == "nccl" else torch.device("cpu"), force=args.force_dist)
 
     if rank == 0:
         value = total_samples / elapsed / 1e6
@@ -423,6 +431,8 @@ def main():
             "preroll_steps": preroll,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if args.streams else "weak",
             "vs_baseline": None, "dtype": "int32",
+            "collectives": ("%s: barrier x2 + all_reduce(MAX time, SUM samples) on %s tensors, world %d" %
+                            (args.backend, "device" if args.backend == "nccl" else "host", world)) if dist is not None else "none (one process)",
             "data": "synthetic: %s, %s, HBM-resident before the timed region" %
                     ("uniform random full-scale int16 IQ (counter-based hash, tests/signals.py)" if args.input == "hash" else
                      "uniform random full-scale int16 IQ (torch.randint)" if args.input == "noise" else "GPU TestSource bank: 10 Msps CW, -20 dB, +100 kHz + 1 kHz x stream id",

@@ -209,7 +209,25 @@ struct DecPlanArgs {
     size_t payload_frame_bytes;
     uint8_t *block0_out;       // may be NULL
     int nframes;
+    uint8_t *plan2;            // [nframes][DEC128_PLAN_BYTES] records for gf_decode128_kernel (NULL: dense path only)
 };
+
+// Per-frame record of the syndrome decoder (gf_decode128_kernel): where every original lies in the received array, which
+// recovery rows came, which originals they restore, and the N x N inverse (N <= 32; bigger repairs take the dense kernel).
+constexpr int DEC128_MAXN = 32;
+struct Dec128Plan {
+    int16_t inv[128];                         // position of original j in the received array, -1 = erased
+    uint8_t rowidx[128];                      // recovery row r (block 128 + r) -> i (array order), 255 = not received
+    uint8_t rpos[DEC128_MAXN];                // position of the i-th received recovery block
+    uint8_t ydst[DEC128_MAXN];                // original restored by row t of the inverse (ascending)
+    uint8_t minv[DEC128_MAXN * DEC128_MAXN];  // Minv[t][i]
+    int32_t n;                                // erased originals to restore here (0: none, or not this kernel's frame)
+    int32_t m1;                               // cm256's DecodeM1: one recovery block, XOR of everything received
+    int32_t maxrow;                           // highest recovery row among the received ones
+    int32_t pad;
+};
+constexpr int DEC128_PLAN_BYTES = (int)sizeof(Dec128Plan);
+static_assert(sizeof(Dec128Plan) % 16 == 0 && sizeof(Dec128Plan) == DECODE_PLAN2_BYTES, "record size (sdrhip_internal.h)");
 
 __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
 {
@@ -254,6 +272,19 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
 
     const int N = nrec;
     bool ok = N > 0 && !dup;
+    Dec128Plan *pl = a.plan2 ? reinterpret_cast<Dec128Plan *>(a.plan2 + (size_t)f * DEC128_PLAN_BYTES) : nullptr;
+    const bool syn = pl && N <= DEC128_MAXN; // this frame's repair (if any) is the syndrome kernel's
+    if (pl) {
+        // (the copy of the received originals is gf_decode128_kernel's job for EVERY frame; a repeated original: any copy)
+        pl->inv[p] = (int16_t)-1;
+        pl->rowidx[p] = 255;
+        if (p == 0) { pl->n = 0; pl->m1 = 0; pl->maxrow = 0; pl->pad = 0; }
+    }
+    __syncthreads();
+    if (pl) {
+        if (b < K) pl->inv[b] = (int16_t)p;
+        else if (ok && syn) { pl->rowidx[b - K] = (uint8_t)rrank; pl->rpos[rrank] = (uint8_t)p; atomicMax(&pl->maxrow, b - K); }
+    }
     if (ok && N >= 2) {
         // logarithm sums of the four products
         if (p < N) {
@@ -282,7 +313,7 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
                 const int den = s_log[xi ^ yt] + s_lqx[i] + s_lqy[t] + s_log[yt ^ K];
                 s_linv[t * K + i] = (uint8_t)((num + 4 * 255 - den) % 255);
             }
-            if (!is_rec)
+            if (!is_rec && !syn)
                 for (int i = 0; i < N; ++i) s_le[i * K + p] = (uint8_t)((s_log[b ^ K] + 255 - s_log[s_x[i] ^ b]) % 255);
         }
         __syncthreads();
@@ -309,7 +340,15 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
             else zd = 0;
         }
         pdst[p] = pd; zdst[p] = zd;
-        if (p == 0) { meta[0] = N; meta[1] = s_y[0] == 0; } // (ascending: block 0, when erased, is row 0)
+        if (p == 0) { meta[0] = syn ? 0 : N; meta[1] = syn ? 0 : s_y[0] == 0; } // (ascending: block 0, when erased, is row 0)
+    }
+    if (syn) {
+        // the syndrome kernel applies the N x N inverse itself: no N x 128 product matrix
+        if (p < N) pl->ydst[p] = s_y[p];
+        if (N == 1) { if (p == 0) { pl->minv[0] = 1; pl->m1 = 1; } }
+        else for (int e = p; e < N * N; e += K) { const int t = e / N, i = e - t * N; pl->minv[t * DEC128_MAXN + i] = s_exp[s_linv[t * K + i]]; }
+        if (p == 0) pl->n = N;
+        return;
     }
     uint8_t *coef = a.coef + (size_t)f * K * K;
     if (N == 1) { // DecodeM1: XOR of everything that was received
@@ -414,6 +453,156 @@ template <int RB> __global__ __launch_bounds__(GF_NT) void gf_decode_apply_kerne
     }
 }
 
+
+// ---- syndrome decoder for 128 originals (round 3).  The dense kernel above multiplies the received blocks with an N x 128
+// matrix per frame (24 x 128 x 508 byte products at 24 erasures).  But what the received originals contribute to the received
+// recovery rows is exactly what the ENCODER computes with the erased originals set to zero -- the XOR-convolution walk of
+// gf_encode128_wg, 2.6 x cheaper per row than dense rows -- and the rest is small: syndrome_i = recovery_i ^ that, and the
+// erased originals are Minv (N x N, closed form, from the planner) times the syndromes: 24 x 24 instead of 24 x 128 products.
+// The kernel reads every received block once and writes it to its place in the payload on the way (the former scatter pass).
+// One workgroup per (frame, half block) like the encoder; lanes = 4-byte columns.
+struct Dec128Args {
+    const uint8_t *rx;          // frames [nframes][128][512] in arrival order
+    size_t rx_frame_bytes;
+    const uint8_t *plan;        // [nframes] Dec128Plan
+    const uint8_t *tab;         // 256 x 32 B multiplier tables
+    const uint8_t *leaf_tables; // Karatsuba leaves of the encoder
+    uint8_t *payload_out;       // [nframes][127 x 508]
+    size_t payload_frame_bytes;
+    uint8_t *block0_out;        // optional [nframes][508]
+    int nframes;
+};
+constexpr int DEC128_LDS_BYTES = 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4 + DEC128_MAXN * 64 * 4 + DEC128_PLAN_BYTES;
+
+#ifndef DEC128_WPE
+#define DEC128_WPE 4
+#endif
+__global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128Args a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ldsraw[DEC128_LDS_BYTES];
+    uint4_t *lt16 = reinterpret_cast<uint4_t *>(ldsraw);
+    unsigned *lt4 = reinterpret_cast<unsigned *>(ldsraw + 8 * KLEAVES * 16);
+    unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + 8 * KLEAVES * 20);                       // all 256 constants: 8 dwords each
+    unsigned (*ysum)[64] = reinterpret_cast<unsigned (*)[64]>(ldsraw + 8 * KLEAVES * 20 + 256 * 32); // convolution rows + parity
+    unsigned (*syn)[64] = reinterpret_cast<unsigned (*)[64]>(ldsraw + 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4);
+    Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4 + DEC128_MAXN * 64 * 4);
+    const int tid = threadIdx.x;
+    const int fr = blockIdx.x >> 1;
+    for (int i = tid; i < 8 * KLEAVES; i += GF_NT) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(a.leaf_tables) + (size_t)i * 8;
+        lt16[i] = (uint4_t){src[0], src[1], src[2], src[3]};
+        lt4[i] = src[4];
+    }
+    for (int i = tid; i < 256 * 8; i += GF_NT) tab[i] = reinterpret_cast<const unsigned *>(a.tab)[i];
+    for (int i = tid; i < DEC128_PLAN_BYTES / 4; i += GF_NT)
+        reinterpret_cast<unsigned *>(pl)[i] = reinterpret_cast<const unsigned *>(a.plan + (size_t)fr * DEC128_PLAN_BYTES)[i];
+    for (int i = tid; i < 33 * 64; i += GF_NT) (&ysum[0][0])[i] = 0;
+    __syncthreads();
+
+    const int w = tid >> 6, lane = tid & 63;
+    const int col = (blockIdx.x & 1) * 64 + lane;
+    const bool live = col < 127;
+    const unsigned *rx = reinterpret_cast<const unsigned *>(a.rx + (size_t)fr * a.rx_frame_bytes) + 1 + (live ? col : 0);
+    unsigned *pay = reinterpret_cast<unsigned *>(a.payload_out + (size_t)fr * a.payload_frame_bytes) + (live ? col : 0);
+    unsigned *b0 = a.block0_out ? reinterpret_cast<unsigned *>(a.block0_out + (size_t)fr * 508) + (live ? col : 0) : nullptr;
+    const int N = pl->n;
+    const int npairs = N > 0 && !pl->m1 ? (pl->maxrow >> 5) + 1 : 1; // (M1 and plain copies: one walk for the parity / the copy)
+
+#pragma unroll 1
+    for (int tp = 0; tp < npairs; ++tp) {
+        unsigned y0[KN], y1[KN];
+#pragma unroll
+        for (int i = 0; i < KN; ++i) { y0[i] = 0; y1[i] = 0; }
+        unsigned p = 0;
+#pragma unroll 1
+        for (int q = 0; q < 2; ++q) {
+            const int cb = 2 * w + q;
+            unsigned v[2 * KN - 1];
+#pragma unroll
+            for (int i = 0; i < KN; ++i) {
+                const int pos = pl->inv[KN * cb + i];
+                v[i] = (pos >= 0 && live) ? SDRHIP_STREAM_LOAD(rx + (size_t)pos * 128) : 0u;
+            }
+            if (tp == 0 && live) {
+                // the received originals go to their places (getSlotData's layout: blocks 1..127 back to back, block 0 apart)
+#pragma unroll
+                for (int i = 0; i < KN; ++i) {
+                    const int j = KN * cb + i;
+                    if (pl->inv[j] >= 0) {
+                        if (j >= 1) pay[(size_t)(j - 1) * 127] = v[i];
+                        else if (b0) b0[0] = v[i];
+                    }
+                }
+            }
+            if (N == 0) continue; // (copy only)
+#pragma unroll
+            for (int i = 0; i < KN; ++i) p ^= v[i];
+            if (pl->m1) continue; // (parity only)
+            const int t0 = (2 * tp) ^ cb, t1 = (2 * tp + 1) ^ cb;
+            acc_conv2<KN, 0, 0, 0>(v, y0, y1, lds_addr(lt16 + t0 * KLEAVES), lds_addr(lt4 + t0 * KLEAVES),
+                                   lds_addr(lt16 + t1 * KLEAVES), lds_addr(lt4 + t1 * KLEAVES));
+        }
+        if (N == 0) return; // (uniform)
+        if (tp == 0) __hip_atomic_fetch_xor(&ysum[32][lane], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!pl->m1) {
+#pragma unroll
+            for (int i = 0; i < KN; ++i) {
+                __hip_atomic_fetch_xor(&ysum[i][lane], y0[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_xor(&ysum[KN + i][lane], y1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        // syndromes of the received recovery rows among rows 32 tp + 8 w .. + 7: recovery ^ (P ^ r * c_r)
+        const unsigned P = ysum[32][lane];
+        if (pl->m1) {
+            if (w == 0) syn[0][lane] = live ? (P ^ SDRHIP_STREAM_LOAD(rx + (size_t)pl->rpos[0] * 128)) : 0u;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int rl = 8 * w + q, r = 32 * tp + rl;
+                const int i = pl->rowidx[r & 127];
+                if (r < 128 && i != 255) {
+                    const uint4_t t = *reinterpret_cast<const uint4_t *>(&tab[r * 8]);
+                    const unsigned rec = live ? SDRHIP_STREAM_LOAD(rx + (size_t)pl->rpos[i] * 128) : 0u;
+                    syn[i][lane] = rec ^ P ^ kmul(ysum[rl][lane], t, tab[r * 8 + 4]);
+                }
+            }
+        }
+        __syncthreads();
+        if (tp + 1 < npairs) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ysum[8 * w + q][lane] = 0;
+            __syncthreads();
+        }
+    }
+    // erased originals = Minv x syndromes: wave w takes rows w, w + 4, ... (up to 8 of them); a syndrome dword is split into its
+    // selector words once and multiplied by the constants of all the wave's rows
+    unsigned acc[DEC128_MAXN / 4];
+#pragma unroll
+    for (int u = 0; u < DEC128_MAXN / 4; ++u) acc[u] = 0u;
+    const int nmine = (N - w + 3) >> 2; // rows w + 4 u < N
+    for (int i = 0; i < N; ++i) {
+        const Sel sl = make_sel(syn[i][lane]);
+#pragma unroll
+        for (int u = 0; u < DEC128_MAXN / 4; ++u) {
+            if (u < nmine) {
+                const int m = pl->minv[(w + 4 * u) * DEC128_MAXN + i];
+                acc[u] ^= mulc(sl, *reinterpret_cast<const uint4_t *>(&tab[m * 8]), tab[m * 8 + 4]);
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int u = 0; u < DEC128_MAXN / 4; ++u) {
+            if (u < nmine) {
+                const int y = pl->ydst[w + 4 * u];
+                if (y >= 1) pay[(size_t)(y - 1) * 127] = acc[u];
+                else if (b0) b0[0] = acc[u];
+            }
+        }
+    }
+}
+
 } // namespace
 
 hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream)
@@ -473,15 +662,28 @@ hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *
     p.rx = rx; p.rx_frame_bytes = rx_frame_bytes; p.indices = indices_dev; p.explog = explog;
     p.coef = d.coef; p.pmap = d.pmap; p.zmap = d.zmap; p.pdst = d.pdst; p.zdst = d.zdst; p.nrec = d.nrec;
     p.payload_out = payload_out; p.payload_frame_bytes = payload_frame_bytes; p.block0_out = block0_out; p.nframes = nframes;
+    p.plan2 = d.plan2;
     hipLaunchKernelGGL(gf_decode_plan_kernel, dim3(nframes), dim3(128), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // received originals into place
-    e = launch_block_scatter(rx, rx_frame_bytes, 512, 4, payload_out, payload_frame_bytes, 508, 0, d.pmap, 128, nframes, stream);
-    if (e != hipSuccess) return e;
-    if (block0_out) {
-        e = launch_block_scatter(rx, rx_frame_bytes, 512, 4, block0_out, 508, 508, 0, d.zmap, 128, nframes, stream);
+    if (d.plan2) {
+        // syndrome decoder: copies the received originals of EVERY frame and restores up to 32 erased ones; frames that need
+        // more (nrec > 0 below) go on to the dense kernel
+        Dec128Args k;
+        k.rx = rx; k.rx_frame_bytes = rx_frame_bytes; k.plan = d.plan2; k.tab = tab; k.leaf_tables = d.leaf_tables;
+        k.payload_out = payload_out; k.payload_frame_bytes = payload_frame_bytes; k.block0_out = block0_out; k.nframes = nframes;
+        hipLaunchKernelGGL(gf_decode128_kernel, dim3(2 * nframes), dim3(GF_NT), 0, stream, k);
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
+        if (max_rows <= DEC128_MAXN) return hipSuccess; // (no frame can need the dense kernel)
+    } else {
+        // received originals into place
+        e = launch_block_scatter(rx, rx_frame_bytes, 512, 4, payload_out, payload_frame_bytes, 508, 0, d.pmap, 128, nframes, stream);
+        if (e != hipSuccess) return e;
+        if (block0_out) {
+            e = launch_block_scatter(rx, rx_frame_bytes, 512, 4, block0_out, 508, 508, 0, d.zmap, 128, nframes, stream);
+            if (e != hipSuccess) return e;
+        }
     }
     // erased originals: rows 0 .. nrec[f] of every frame's matrix (workgroups beyond a frame's count leave at once)
     DecApplyArgs a;

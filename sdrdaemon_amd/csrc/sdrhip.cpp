@@ -118,7 +118,8 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
         // the environment is read here, once (getenv is not safe against a concurrent setenv): later changes go through
         // sdrhip_ctx_set_option()
         static const char *const keys[][2] = {{"SDRHIP_DECIM_PATH", "decim_path"}, {"SDRHIP_MFMA_SPAN", "mfma_span"}, {"SDRHIP_MFMA_MIN", "mfma_min"},
-                                              {"SDRHIP_INTERP_PATH", "interp_path"}, {"SDRHIP_INTERP_SPAN", "interp_span"}, {"SDRHIP_RX_FUSED", "rx_fused"}};
+                                              {"SDRHIP_INTERP_PATH", "interp_path"}, {"SDRHIP_INTERP_SPAN", "interp_span"}, {"SDRHIP_RX_FUSED", "rx_fused"},
+                                              {"SDRHIP_DEC_PATH", "dec_path"}};
         for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); ++i)
             if (const char *v = getenv(keys[i][0])) (void)sdrhip_ctx_set_option(c, keys[i][1], v);
     }
@@ -188,6 +189,11 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
     else if (k == "mfma_min" && isnum) c->opt.mfma_min = (size_t)num;
     else if (k == "interp_span" && isnum) c->opt.interp_span = (size_t)num;
     else if (k == "rx_fused" && isnum) c->opt.rx_fused = (int)num;
+    else if (k == "dec_path") {
+        if (v == "syndrome") c->opt.dec_syndrome = 1;
+        else if (v == "dense") c->opt.dec_syndrome = 0;
+        else return fail(SDRHIP_EINVAL, "ctx_set_option: dec_path must be syndrome or dense");
+    } else if (k == "dec_max_rows" && isnum && num >= 1 && num <= 128) c->opt.dec_max_rows = (int)num;
     else return fail(SDRHIP_EINVAL, "ctx_set_option: unknown key or malformed value: %s=%s", key, value);
     return SDRHIP_OK;
 }

@@ -88,7 +88,10 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
     d.zmap = reinterpret_cast<int16_t *>(base); base += nframes * 128 * sizeof(int16_t);
     d.pdst = reinterpret_cast<int16_t *>(base); base += nframes * 128 * sizeof(int16_t);
     d.zdst = reinterpret_cast<int16_t *>(base); base += nframes * 128 * sizeof(int16_t);
-    d.nrec = reinterpret_cast<int32_t *>(base);
+    d.nrec = reinterpret_cast<int32_t *>(base); base += (nframes * 2 * sizeof(int32_t) + 15) & ~(size_t)15;
+    // syndrome decoder (default) or the dense matrix kernel alone (ctx option dec_path = dense: A / B and fallback)
+    d.plan2 = c->opt.dec_syndrome ? base : nullptr;
+    d.leaf_tables = c->enc_leaves;
     const uint8_t *idx_dev = nullptr;
     if (indices) {
         const size_t nb = nframes * (size_t)SDRHIP_NB_ORIGINAL;
@@ -103,7 +106,7 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
     {
         KTimer kt(c, SDRHIP_K_FEC_DECODE);
         e = launch_fec_decode_device_plan(d, rx, rx_frame_bytes, idx_dev, c->gf_explog, c->gf_tab, (int)nframes, payload_out,
-                                          payload_frame_bytes, block0_out, 128, c->stream);
+                                          payload_frame_bytes, block0_out, c->opt.dec_max_rows, c->stream);
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec decode launch: %s", hipGetErrorString(e));
     return SDRHIP_OK;

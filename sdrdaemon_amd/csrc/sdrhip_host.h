@@ -104,7 +104,9 @@ struct CtxOptions {
     size_t mfma_min = (size_t)1 << 22;     // smallest call (samples over all streams, decimate4 / 8) the matrix cores take in auto mode
     int interp_mfma = 0;
     size_t interp_span = 0;
-    int rx_fused = 1;                      // Rx pipe: encoder in the decimator's launch (0 = separate launches)
+    int rx_fused = 1;                      // pipelined Rx pipe: encoder in the decimator's launch (0 = separate launches)
+    int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)
+    int dec_max_rows = 128;                // upper bound of the recovery blocks a received frame can have used (the sender's fecblk)
 };
 // what the last decimate / rx call of a bank actually launched (sdrhip_decimators_last_plan)
 struct DecimPlanInfo {

@@ -225,12 +225,15 @@ hipError_t launch_fec_headers(const uint8_t *frames, size_t in_frame_bytes, uint
 
 
 // device-side decode planning (gf_kernels.hip): work buffers of a batch of nframes
+constexpr size_t DECODE_PLAN2_BYTES = 1488; // sizeof(Dec128Plan), gf_kernels.hip
 struct DecodeBuffers {
     uint8_t *coef;            // [nframes][128][128]
     int16_t *pmap, *zmap;     // [nframes][128]
     int16_t *pdst, *zdst;     // [nframes][128]
     int32_t *nrec;            // [nframes][2]
-    static size_t bytes(size_t nframes) { return nframes * (128 * 128 + 4 * 128 * sizeof(int16_t) + 2 * sizeof(int32_t)) + 64; }
+    uint8_t *plan2;           // [nframes][DECODE_PLAN2_BYTES] records of the syndrome decoder, NULL = dense path only
+    const uint8_t *leaf_tables; // Karatsuba leaf tables of the 128-original encoder (the syndrome decoder walks the same tree)
+    static size_t bytes(size_t nframes) { return nframes * (128 * 128 + 4 * 128 * sizeof(int16_t) + 2 * sizeof(int32_t) + DECODE_PLAN2_BYTES) + 64; }
 };
 // plan + scatter + apply, all on the stream, no host synchronisation; max_rows = upper bound of the recovery blocks a
 // frame can have used (128 when unknown)

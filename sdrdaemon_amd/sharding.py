@@ -21,9 +21,10 @@ def owner(stream_id, streams_per_gpu):
     return stream_id // streams_per_gpu
 
 
-def aggregate(elapsed_s, samples, dist=None, device=None):
-    """-> (max elapsed over ranks, total samples over ranks).  dist = torch.distributed or None."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def aggregate(elapsed_s, samples, dist=None, device=None, force=False):
+    """-> (max elapsed over ranks, total samples over ranks).  dist = torch.distributed or None.  force: run the two
+    reductions on a world of one as well (the RCCL smoke test of the N = 1 box)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return float(elapsed_s), float(samples)
     import torch
 

@@ -88,3 +88,24 @@ def test_bench_two_ranks_execute_on_one_gpu(extra, scaling, total):
     # value = all ranks' samples / the slowest rank's time
     assert res["value"] == pytest.approx(total * n * 3 / (res["ms_per_step"] * 3e-3) / 1e6, rel=1e-3)
     assert res["value"] > 1000.0
+
+
+@pytest.mark.gpu
+def test_bench_executes_the_rccl_branch_on_one_gpu():
+    """bench.py --force-dist: a world of ONE rank through init_process_group("nccl", device_id=...), two barriers and the two
+    device-tensor all_reduce calls of sharding.aggregate(): the RCCL code path of the driver's 8-GPU run, executed.
+    What it cannot show: more than one GPU -- unmeasured on multi-GPU hardware until a SCALE_r*.json exists."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "3", "--warmup", "1",
+           "--cpu-seconds", "0", "--preroll-seconds", "0.05", "--log2-samples", "22", "--no-configs", "--no-verify"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["collectives"].startswith("nccl")
+    assert res["value"] == pytest.approx(8 * (1 << 22) * 3 / (res["ms_per_step"] * 3e-3) / 1e6, rel=1e-3)

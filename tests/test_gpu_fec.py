@@ -226,3 +226,57 @@ def test_frame_encoder_every_row_count(ctx, oracle, R):
     rec = sd.fec_encode_frames(ctx, frames, R)
     for f in range(F):
         assert np.array_equal(rec[f], oracle.frame_encode(frames[f], R)), (R, f)
+
+
+def test_syndrome_decoder_equals_dense_decoder_on_hostile_batches(ctx, oracle):
+    """The batched decoder's two device paths -- syndrome kernel (encoder walk over the received originals + N x N inverse,
+    default) and the dense N x 128 matrix kernel -- on frames that exercise every branch of the planner: 0 .. 40 erasures
+    (> 32: the syndrome path hands the frame to the dense kernel), high recovery rows (sender fecblk 128), block 0 erased,
+    cm256's one-recovery-block XOR shortcut on a row that is not the parity row, repeated originals and repeated recovery
+    blocks (cm256's decode error: the frame keeps what was received), arrival order shuffled.  Both must give the same
+    bytes; the decodable ones must give back the originals."""
+    import sdrdaemon_amd as sd
+
+    R, F = 128, 64
+    rs = np.random.RandomState(2024)
+    x = signals.noise(F * 16129, 77)
+    frames = oracle.framer(nb_fec_blocks=127).write(x)
+    frames[:, :, 3] = 0
+    rx = np.zeros((F, 128, 512), np.uint8)
+    decodable = np.ones(F, bool)
+    for f in range(F):
+        allb = np.concatenate([frames[f], oracle.frame_encode(frames[f], R)])
+        kind = f % 8
+        nlost = [0, 1, 3, 24, 32, 33, 40, 17][kind]
+        lost_o = sorted(rs.choice(128, nlost, replace=False).tolist())
+        if kind == 2:
+            lost_o[0] = 0  # block 0 among the erased
+            lost_o = sorted(set(lost_o))
+        rows = sorted(rs.choice(128, len(lost_o), replace=False).tolist())  # any recovery rows, not the first ones
+        if kind == 1:
+            rows = [int(rs.randint(1, 128))]  # M1 shortcut with a non-parity row: cm256 XORs anyway (wrong bytes, mirrored)
+            decodable[f] = False
+        got = [i for i in range(128) if i not in lost_o]
+        rs.shuffle(got)
+        order = got + [128 + r for r in rows]
+        if kind == 7 and f % 16 == 7:
+            order[3] = order[4]  # a repeated original
+            decodable[f] = False
+        if kind == 7 and f % 16 == 15:
+            order[-1] = order[-2]  # the same recovery block twice
+            decodable[f] = False
+        rx[f] = allb[order]
+    outs = {}
+    for path in ("dense", "syndrome"):
+        ctx.set_option("dec_path", path)
+        try:
+            outs[path] = sd.fec_decode_frames(ctx, rx, want_block0=True)
+        finally:
+            ctx.set_option("dec_path", "syndrome")
+    for k in (0, 1):
+        assert np.array_equal(outs["dense"][k], outs["syndrome"][k]), ("payload", "block0")[k]
+    payload, b0 = outs["syndrome"]
+    for f in range(F):
+        if decodable[f]:
+            assert np.array_equal(payload[f].view(np.int16).reshape(-1, 2), x[f * 16129:(f + 1) * 16129]), f
+            assert np.array_equal(b0[f], frames[f, 0, 4:]), f

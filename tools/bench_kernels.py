@@ -13,6 +13,8 @@ from sdrdaemon_amd.engine import K_DECIMATE, K_FEC_DECODE, K_FEC_ENCODE, K_INTER
 
 what = sys.argv[1:] or ["decim", "interp", "fec"]
 ctx = sd.Context(0)
+if os.environ.get("SDRHIP_DEC_MAX"):
+    ctx.set_option("dec_max_rows", os.environ["SDRHIP_DEC_MAX"])
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
 S = 8
