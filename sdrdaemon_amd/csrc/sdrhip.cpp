@@ -183,7 +183,13 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
         else return fail(SDRHIP_EINVAL, "ctx_set_option: decim_path must be auto, valu or mfma");
     } else if (k == "interp_path") {
         if (v == "valu" || v == "auto") c->opt.interp_mfma = 0;
-        else if (v == "mfma") c->opt.interp_mfma = 1;
+        else if (v == "mfma") {
+#ifdef SDRHIP_WITH_K5M
+            c->opt.interp_mfma = 1;
+#else
+            return fail(SDRHIP_EINVAL, "ctx_set_option: this library was built without the matrix-core interpolator experiment (make WITH_K5M=1)");
+#endif
+        }
         else return fail(SDRHIP_EINVAL, "ctx_set_option: interp_path must be valu or mfma");
     } else if (k == "mfma_span" && isnum) c->opt.mfma_span = (size_t)num;
     else if (k == "mfma_min" && isnum) c->opt.mfma_min = (size_t)num;
@@ -212,6 +218,7 @@ static void sdrhip::ctx_free(sdrhip_ctx *c)
     if (c->gf_explog) (void)hipFree(c->gf_explog);
     c->dec_plan.release();
     c->pin.release();
+    c->zin.release(); c->zout.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -472,6 +479,17 @@ extern "C" int sdrhip_decimate(sdrhip_decimators *d, int log2decim, int fcpos, u
     if (n_in == 0) // nothing to stage; sampleSize still advances like in the device path
         return decimate_device(d, log2decim, fcpos, sampleSize, nullptr, 0, 0, nullptr, 0, n_out, 0, 0, 0);
     int rc;
+    if ((size_t)S * dis * 4 <= SDRHIP_ZEROCOPY_MAX) {
+        // small call (one TestSource block ...): no copy engine, the kernel reads and writes pinned host memory itself
+        if ((rc = c->zin.reserve((size_t)S * dis * 4 + 16))) return rc;
+        if ((rc = c->zout.reserve((size_t)S * dos * 4 + 16))) return rc;
+        for (int s = 0; s < S; ++s) memcpy(c->zin.as<int16_t>() + (size_t)s * dis * 2, iq_in + (size_t)s * in_stride * 2, n_in * 4);
+        rc = decimate_device(d, log2decim, fcpos, sampleSize, c->zin.as<int16_t>(), n_in, dis, c->zout.as<int16_t>(), dos, n_out, 0, 0, 0);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int s = 0; s < S && n_res; ++s) memcpy(iq_out + (size_t)s * out_stride * 2, c->zout.as<int16_t>() + (size_t)s * dos * 2, n_res * 4);
+        return SDRHIP_OK;
+    }
     if ((rc = c->in.reserve((size_t)S * dis * 4 + 16))) return rc;
     if ((rc = c->out.reserve((size_t)S * dos * 4 + 16))) return rc;
     HIP_TRY(hipMemcpy2DAsync(c->in.p, dis * 4, iq_in, in_stride * 4, n_in * 4, S, hipMemcpyHostToDevice, c->stream));

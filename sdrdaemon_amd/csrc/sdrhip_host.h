@@ -42,6 +42,11 @@ struct PinnedBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// host-pointer calls up to this many input bytes skip the copy engine: the input is memcpy'd into pinned host memory that the
+// kernel reads over PCIe itself, small outputs are written the same way (one launch + one sync instead of H2D + launch + D2H + sync:
+// 42 -> ~28 us for one 65 536-sample TestSource block, tools/bench_host_block.py)
+constexpr size_t SDRHIP_ZEROCOPY_MAX = (size_t)384 << 10; // (measured: 256 KiB calls 42 -> 29 us, 1 MiB calls 59 -> 77 us: the copy engine wins from there)
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 void ctx_retain(sdrhip_ctx *c);
@@ -138,6 +143,7 @@ struct sdrhip_ctx {
     uint8_t *gf_explog = nullptr;             // exp[512] + log[256] (uint16) of GF(256) for the decode planner (device)
     sdrhip::DevBuf dec_plan;                  // per-frame decode plans of the current batch (DecodeBuffers)
     sdrhip::PinnedBuf pin;                       // per-call upload staging (maps, frame lists)
+    sdrhip::PinnedBuf zin, zout;                 // zero-copy staging of small host-pointer calls (the kernels read / write pinned host memory)
     // per-kernel-class timing with hipEvents on `stream` (sdrhip_ctx_kernel_timing)
     bool ktime_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> kev[4];

@@ -70,10 +70,32 @@ struct DecimArgs {
 // MetaDataFEC of the fi-th frame a call starts (UDPSinkFEC.cpp:90-115: the reference takes gettimeofday() when it opens a
 // frame and CRCs the first 20 bytes).  A batched call opens all its frames "at once", so the stamp of a frame is the
 // call's stamp (base[3] = tv_sec, base[4] = tv_usec: the time of the call's first sample) advanced by the sample clock:
-// frame fi starts idx0 + fi * 16129 samples into the call, i.e. floor(idx * 10^6 / rate) microseconds later.  CRC-32
-// (boost::crc_32_type = reflected 0xEDB88320) bit-serially over the five little-endian words: ~500 scalar instructions
-// per frame, wave-uniform.  (The test-side framer applies the same rule: DESIGN.md K2.)
-#ifdef __HIPCC__
+// frame fi starts idx0 + fi * 16129 samples into the call, i.e. floor(idx * 10^6 / rate) microseconds later.
+// CRC-32 (boost::crc_32_type = reflected 0xEDB88320) of the stamped record: the CRC is affine over GF(2), so
+// crc(record) = crc(record with a zero stamp) ^ XOR over the set stamp bits k of CRC_BIT[k]; the first term comes from the host
+// (base[5]), CRC_BIT[k] = the zero-init CRC of the 20-byte message that has only stamp bit k set (compile-time table).  Lane k
+// of a wave looks at bit k, six DPP / swizzle steps XOR-reduce: ~25 instructions per frame instead of a 160-step bit-serial
+// loop (which doubled the framing kernel's time).  Must be called by whole waves.  (The test-side framer applies the same
+// rule: DESIGN.md K2.)
+#if defined(__HIPCC__) && __cplusplus >= 201703L // (the kernels' translation units: C++17; the host files are C++11)
+struct CrcBitTable { unsigned c[64]; };
+constexpr CrcBitTable make_crc_bit_table()
+{
+    CrcBitTable T{};
+    for (int k = 0; k < 64; ++k) {
+        unsigned crc = 0u;
+        for (int byte = 0; byte < 20; ++byte) {
+            unsigned v = 0u;
+            if (byte >= 12 && byte == 12 + k / 8) v = 1u << (k % 8);
+            crc ^= v;
+            for (int b = 0; b < 8; ++b) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+        }
+        T.c[k] = crc;
+    }
+    return T;
+}
+__device__ const CrcBitTable CRC_BIT = make_crc_bit_table();
+
 __device__ __forceinline__ void frame_meta_words(const unsigned (&base)[6], uint64_t idx0, unsigned rate, int fi, unsigned (&w)[6])
 {
     unsigned sec = base[3], usec = base[4];
@@ -86,14 +108,12 @@ __device__ __forceinline__ void frame_meta_words(const unsigned (&base)[6], uint
         if (usec >= 1000000u) { usec -= 1000000u; sec += 1u; }
     }
     w[0] = base[0]; w[1] = base[1]; w[2] = base[2]; w[3] = sec; w[4] = usec;
-    unsigned crc = 0xFFFFFFFFu;
-#pragma unroll 1
-    for (int k = 0; k < 5; ++k) {
-        crc ^= w[k];
-#pragma unroll 8
-        for (int b = 0; b < 32; ++b) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
-    }
-    w[5] = ~crc;
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned word = lane < 32 ? sec : usec;
+    unsigned x = ((word >> (lane & 31)) & 1u) ? CRC_BIT.c[lane] : 0u;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x ^= (unsigned)__shfl_xor((int)x, m, 64);
+    w[5] = base[5] ^ x;
 }
 #endif
 

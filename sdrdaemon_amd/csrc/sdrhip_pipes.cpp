@@ -78,13 +78,19 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
     // SDRHIP_INTERP_PATH=mfma selects the matrix-core cascade (interp_mfma.hip, DESIGN.md "K5m": bit-exact but slower
     // than the VALU kernel, kept as a measured experiment); SDRHIP_INTERP_SPAN = span length in inputs (tests)
     bool use_mfma = false;
+#ifdef SDRHIP_WITH_K5M
     if (c->opt.interp_mfma) use_mfma = plan_interpolate_mfma(log2interp, n_in, p->nstreams, c->opt.interp_span, &a);
+#endif
     if (!use_mfma) plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
     a.mf_dump = c->decim_dump;
     hipError_t e;
     {
         KTimer kt(c, SDRHIP_K_INTERPOLATE);
+#ifdef SDRHIP_WITH_K5M
         e = use_mfma ? launch_interpolate_mfma(log2interp, a, c->stream) : launch_interpolate(log2interp, a, c->stream);
+#else
+        e = launch_interpolate(log2interp, a, c->stream);
+#endif
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "interpolate launch: %s", hipGetErrorString(e));
     p->cur ^= 1;
@@ -336,9 +342,17 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     int rc;
     if (mem == SDRHIP_MEM_HOST) {
         dstride = (n_in + 3) & ~(size_t)3;
-        if ((rc = c->in.reserve((size_t)S * dstride * 4 + 16))) return rc;
-        HIP_TRY(hipMemcpy2DAsync(c->in.p, dstride * 4, iq_in, in_stride * 4, n_in * 4, S, hipMemcpyHostToDevice, c->stream));
-        din = c->in.as<int16_t>();
+        if ((size_t)S * dstride * 4 <= SDRHIP_ZEROCOPY_MAX) {
+            // small call: the decimator reads pinned host memory itself (no copy engine in front of the launch); the buffer is
+            // free again when this call returns (host-pointer calls end with a stream synchronisation)
+            if ((rc = c->zin.reserve((size_t)S * dstride * 4 + 16))) return rc;
+            for (int s = 0; s < S; ++s) memcpy(c->zin.as<int16_t>() + (size_t)s * dstride * 2, iq_in + (size_t)s * in_stride * 2, n_in * 4);
+            din = c->zin.as<int16_t>();
+        } else {
+            if ((rc = c->in.reserve((size_t)S * dstride * 4 + 16))) return rc;
+            HIP_TRY(hipMemcpy2DAsync(c->in.p, dstride * 4, iq_in, in_stride * 4, n_in * 4, S, hipMemcpyHostToDevice, c->stream));
+            din = c->in.as<int16_t>();
+        }
     } else if (mem == SDRHIP_MEM_DEVICE) {
         if (!aligned16(iq_in) || (S > 1 && (in_stride & 3))) return fail(SDRHIP_EALIGN, "rx_process: device input must be 16-byte aligned");
     } else {
@@ -398,7 +412,14 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         // tv_sec / tv_usec = the stamp of the call's first sample; a frame's own stamp (the reference calls gettimeofday when it
         // opens the frame, UDPSinkFEC.cpp:90-104) is that plus its first sample's offset on the sample clock, and the
         // boost::crc_32_type over the first 20 bytes (:106-109) follows from it: both per frame on the device (frame_meta_words)
-        const uint32_t crc = 0;
+        // (m[20..23] = the CRC of the record with a ZERO stamp: the affine part of the per-frame CRC, see frame_meta_words)
+        memset(m + 12, 0, 8);
+        uint32_t crc = 0xFFFFFFFFu;
+        for (int i = 0; i < 20; ++i) {
+            crc ^= m[i];
+            for (int k = 0; k < 8; ++k) crc = (crc & 1) ? 0xEDB88320u ^ (crc >> 1) : crc >> 1;
+        }
+        crc ^= 0xFFFFFFFFu;
         memcpy(m + 12, &tv_sec, 4); memcpy(m + 16, &tv_usec, 4); memcpy(m + 20, &crc, 4);
         meta.first = first_new; meta.count = started; meta.frame_count0 = (unsigned)rx->frame_count + first_new;
         memcpy(meta.w, m, 24);

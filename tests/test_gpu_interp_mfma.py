@@ -21,7 +21,12 @@ def ctx():
 
 @pytest.fixture()
 def mfma_path(ctx):
-    ctx.set_option("interp_path", "mfma")
+    import sdrdaemon_amd as sd
+
+    try:
+        ctx.set_option("interp_path", "mfma")
+    except sd.SdrHipError:
+        pytest.skip("K5m (matrix-core interpolator experiment) is not in the product library: make -C sdrdaemon_amd/csrc WITH_K5M=1")
 
     def span(n):
         ctx.set_option("interp_span", n)
