@@ -232,6 +232,18 @@ def extra_configs(ctx, dev, x, kind):
                 "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
                 "roofline": roof(BYTES_DECIM * S * n, per[K_DECIMATE], decim_kernel_name(d.last_plan()))})
     del y
+    # the headline workload through the pipelined plumbing (sdrhip_rx_set_pipelined: frames delivered one call late, the encoder of
+    # call i - 1 inside the decimator launch of call i).  Steady state: every timed step holds one decimation and one encode.
+    rxp = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                    center_frequency_khz=435000, sample_rate=625000, pipelined=True)
+    wall, per = timed_steps(ctx, lambda: rxp.process_view(x, tv_sec=1, tv_usec=0), [K_DECIMATE])
+    rxp.flush_view()
+    out.append({"config": "configs[2] x %d streams, pipelined plumbing: frames delivered one call late, CM256 encoder workgroups inside the "
+                          "decimator's launch (rx_fused_kernel)" % S,
+                "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
+                "roofline": roof(BYTES_CONFIG3 * S * n, per[K_DECIMATE], "rx_fused_kernel<4,true> (decimator + encoder of the previous call: "
+                                                                          "config-3 algorithmic bytes, 4.317 B per sample)")})
+    del rxp
     # configs[2] literally: ONE stream (2^27 samples per step) through the fused Rx pipe
     n1 = 1 << 27
     x1 = make_input(ctx, dev, n1, [4000], kind)
