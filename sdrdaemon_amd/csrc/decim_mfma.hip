@@ -320,6 +320,26 @@ template <int NS, int I> __device__ __forceinline__ void mf_front(MfState<NS> &s
     f.ev_lo = cur_lo; f.ev_hi = cur_hi;
 }
 
+// The same front end fed from LDS: both lanes of an I / Q pair read BOTH 16-byte pieces of their column's step (first half rA,
+// second half rB; the same addresses: an LDS broadcast) and pick their own component -- no exchange with the neighbour (2 DPP moves
+// and 2 v_perm less per step: VALU issue is what bounds the kernel; the second ds_read_b128 issues on the LDS port).
+#ifndef MF_FRONT2
+#define MF_FRONT2 0 // measured (tools/exp25.sh, 4 interleaved rounds): 0.2359-0.2381 ms with it, 0.2356-0.2412 without: 4 VALU fewer per step
+                    // change nothing -- with the DMA ring the kernel sits on its memory skeleton (0.225 ms with its stores), not on VALU issue
+#endif
+template <int NS, int I> __device__ __forceinline__ void mf_front2(MfState<NS> &st, const MfConst &k, MfFront &f, const uint4_t rA, const uint4_t rB)
+{
+    constexpr int i = I;
+    const unsigned aoA = perm(rA.w, rA.y, f.sel_own), aoB = perm(rB.w, rB.y, f.sel_own);
+    const unsigned aeA = perm(rA.z, rA.x, f.sel_own), aeB = perm(rB.z, rB.x, f.sel_own);
+    st.O[0][0][i & 3] = (int)(perm(aoA, aoB, 0x01000504u) ^ 0x80808080u);
+    st.O[0][1][i & 3] = (int)perm(aoA, aoB, 0x03020706u);
+    const unsigned cur_lo = perm(aeA, aeB, 0x01000504u) ^ 0x80808080u, cur_hi = perm(aeA, aeB, 0x03020706u);
+    st.O[0][0][(i + 1) & 3] = (int)perm(cur_lo, f.ev_lo, k.selA);
+    st.O[0][1][(i + 1) & 3] = (int)perm(cur_hi, f.ev_hi, k.selA);
+    f.ev_lo = cur_lo; f.ev_hi = cur_hi;
+}
+
 // ---- LDS-DMA input ring (round 3).  Measured on the register ring above (8 x 2^25, decimate16): arithmetic alone 0.201 ms, the
 // memory skeleton alone 0.206-0.238 ms, both together 0.240 ms: with ONE wave per SIMD nothing covers a wave's s_waitcnt (33 %
 // of its cycles), and a second wave per SIMD does not help because the SIMD's issue port is what the arithmetic saturates.  So
@@ -338,7 +358,9 @@ template <int NS, int I> __device__ __forceinline__ void mf_front(MfState<NS> &s
 #endif
 constexpr int MF_GROUP_BYTES = 9216;             // 8 blocks of 1 KiB + their skew
 constexpr int MF_WAVE_RING = 4 * MF_GROUP_BYTES; // bytes of LDS per wave
-__host__ __device__ constexpr bool mf_dma_applies(int ns) { return MF_DMA && ns >= 4; } // (period of 32 steps; one workgroup per CU)
+// decimate16 only: measured with 3 interleaved rounds (tools/exp24.sh), register ring against LDS-DMA ring: decimate16 0.2445 / 0.2363 ms,
+// decimate32 0.2512 / 0.2537, decimate64 0.2693 / 0.2947 (their warm-up and the ring's run-ahead past the span grow with the ratio)
+__host__ __device__ constexpr bool mf_dma_applies(int ns) { return MF_DMA && ns == 4; } // (period of 32 steps; one workgroup per CU)
 __host__ __device__ constexpr int mf_block_units(int p) { return 72 * p + 2 * (p >> 2); }
 
 template <int SLOT, int D> __device__ __forceinline__ void mf_dma_issue(unsigned ring, unsigned voff, unsigned long long span_base)
@@ -467,7 +489,7 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
     }
     // what this lane reads back: bytes 128 j + 64 comp + 16 q of step j of span p
     const __attribute__((address_space(3))) char *lrd =
-        (const __attribute__((address_space(3))) char *)(size_t)(ring + 16u * (unsigned)(mf_block_units(0) + 72 * p + 2 * (p >> 2) + 4 * comp + q));
+        (const __attribute__((address_space(3))) char *)(size_t)(ring + 16u * (unsigned)(mf_block_units(0) + 72 * p + 2 * (p >> 2) + (MF_FRONT2 ? 0 : 4 * comp) + q));
     unsigned voff[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) voff[g] = 16u * (unsigned)lane + 1024u * (unsigned)(g == 3 ? 3 : g + 4);
@@ -481,12 +503,18 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
     }
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // group 0 has landed
     uint4_t r = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd);
+#if MF_FRONT2
+    uint4_t r2 = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd + 64);
+#endif
     for (int per = 0; per < nper; ++per) {
         oc.store = per >= WP;
         mf_static_for<P>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int i1 = (i + 1) % P;
             if constexpr (i1 % 8 == 0) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); // the next group has landed
+#if MF_FRONT2
+            const uint4_t rn2 = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd + (i1 / 8) * MF_GROUP_BYTES + 128 * (i1 % 8) + 64);
+#endif
 #if MF_ABL & 1024 // (timing experiment: no read-back from the ring)
             uint4_t rn = r;
             asm volatile("" : "+v"(rn));
@@ -500,11 +528,16 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
             if constexpr (i % 8 == 7) voff[g] += 4096u;
 #if MF_ABL & 16
             asm volatile("" : "+v"(st.O[0][0]), "+v"(st.O[0][1]) : "v"(r));
+#elif MF_FRONT2
+            mf_front2<NS, i>(st, k, fr, r, r2);
 #else
             mf_front<NS, i>(st, k, fr, r);
 #endif
             mf_stage<NS, 0, i>(st, k, oc, comp);
             r = rn;
+#if MF_FRONT2
+            r2 = rn2;
+#endif
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no DMA may outlive the workgroup's LDS allocation
