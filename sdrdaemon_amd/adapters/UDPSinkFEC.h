@@ -187,9 +187,13 @@ private:
             int queued;
             {
                 std::unique_lock<std::mutex> lk(m_mutex);
-                while (m_queued == 0 && m_running) m_cond.wait(lk);
+                // like the reference's thread, a frame leaves when the NEXT one is complete: write() stores the index of the
+                // frame it just finished in m_txIndexCurrent and transmitUDP waits while that equals the frame it is about to
+                // process (UDPSinkFEC.cpp:160,206-211) -- so the newest finished frame always stays behind (and the last frame of
+                // a run is never sent, there as here)
+                while (m_queued < 2 && m_running) m_cond.wait(lk);
                 if (!m_running) return;
-                queued = m_queued;
+                queued = m_queued - 1;
             }
             // the waiting frames with the same fecblk as the first one: one GPU call for all of them
             int nb = m_slots[m_send].nbBlocksFEC;

@@ -140,7 +140,12 @@ extern "C" int sdrhip_testsource_configure(sdrhip_testsource *t, int stream, con
     if (stream < -1 || stream >= t->nstreams) return fail(SDRHIP_EINVAL, "testsource_configure: stream out of range");
     CtxLock lock_(t->ctx);
     std::map<std::string, std::string> m = parse_kv(kv);
-    for (int s = (stream < 0 ? 0 : stream); s < (stream < 0 ? t->nstreams : stream + 1); ++s) {
+    // all addressed streams are validated before any of them changes (a range that depends on a stream's own sample rate must
+    // not leave the bank half updated); the one thing the reference commits before it can fail is m_fcPos (TestSource.cpp:175-186
+    // stores it, the decim check comes after, :188-197): a valid fcpos survives an invalid decim, here as well
+    const int s_begin = stream < 0 ? 0 : stream, s_end = stream < 0 ? t->nstreams : stream + 1;
+    std::vector<Gen> fresh((size_t)(s_end - s_begin));
+    for (int s = s_begin; s < s_end; ++s) {
         Gen g = t->gen[(size_t)s];
         unsigned sample_rate = g.srate, frequency = g.conf_freq;
         bool ch_srate = false, ch_freq = false, ch_phase = false, dfp = false;
@@ -186,7 +191,11 @@ extern "C" int sdrhip_testsource_configure(sdrhip_testsource *t, int stream, con
         }
         if (m.count("decim")) {
             const int d = atoi(m["decim"].c_str());
-            if (d < 0 || d > 6) return fail(SDRHIP_EINVAL, "Invalid log2 decimation factor");
+            if (d < 0 || d > 6) {
+                if (m.count("fcpos")) // (validated above, the same for every stream)
+                    for (int u = s_begin; u < s_end; ++u) t->gen[(size_t)u].fcpos = g.fcpos;
+                return fail(SDRHIP_EINVAL, "Invalid log2 decimation factor");
+            }
             g.decim = d;
         }
         g.conf_freq = frequency;
@@ -197,8 +206,9 @@ extern "C" int sdrhip_testsource_configure(sdrhip_testsource *t, int stream, con
         if (ch_srate) g.srate = sample_rate;
         if (ch_freq) g.freq = (unsigned)tuner;
         if (ch_phase) g.inc = inc;
-        t->gen[(size_t)s] = g;
+        fresh[(size_t)(s - s_begin)] = g;
     }
+    for (int s = s_begin; s < s_end; ++s) t->gen[(size_t)s] = fresh[(size_t)(s - s_begin)];
     return SDRHIP_OK;
 }
 

@@ -83,6 +83,13 @@ def test_configure_mirrors_the_reference(ctx):
     assert ts.get(1)["sample_rate"] == 64000  # the other stream is untouched
     assert ts.configure("srate=250000")       # stream = -1: every stream
     assert ts.get(0)["sample_rate"] == ts.get(1)["sample_rate"] == 250000
+    # the reference stores m_fcPos before it checks decim (TestSource.cpp:175-197): a valid fcpos survives an invalid decim ...
+    assert not ts.configure("fcpos=2,decim=9") and "Invalid log2 decimation factor" in ts.error()
+    assert ts.get(0)["fcpos"] == ts.get(1)["fcpos"] == 2 and ts.get(0)["decim"] == 4
+    # ... and a message for every stream that one stream must reject (dfp beyond ITS srate / 2) changes none of them
+    assert ts.configure("srate=48000", 1)
+    assert not ts.configure("dfp=100000,power=3") and "Invalid positive carrier offset" in ts.error()
+    assert ts.get(0)["sample_rate"] == 250000 and ts.get(1)["sample_rate"] == 48000
 
 
 def test_rx_pipe_fed_by_the_bank(ctx, oracle):

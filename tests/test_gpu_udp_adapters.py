@@ -55,7 +55,9 @@ def exe(tmp_path_factory):
 @pytest.mark.parametrize("nb_fec,chunk", [(32, 4096), (8, 16129 + 77), (0, 1000)])
 def test_udpsinkfec_datagrams(exe, oracle, tmp_path, nb_fec, chunk):
     nframes = 3
-    x = signals.mixed(nframes * 16129 + 500, 21 + nb_fec)  # the tail stays in the open frame
+    # one more frame than will arrive: like the reference's transmit thread the adapter's sends frame i when frame i + 1 is
+    # complete (UDPSinkFEC.cpp:160,206-211); the tail stays in the open frame
+    x = signals.mixed((nframes + 1) * 16129 + 500, 21 + nb_fec)
     fin = str(tmp_path / "in.bin")
     x.tofile(fin)
     port = _free_port()
@@ -156,7 +158,7 @@ def test_udpsinkfec_without_gpu_sends_the_originals(exe, tmp_path):
     """CPU: no device -> no recovery blocks (the reference's `!cm256Valid` branch, UDPSinkFEC.cpp:218-225); framing,
     meta block, CRC, pacing thread and sockets still have to be right."""
     nframes = 2
-    x = signals.mixed(nframes * 16129 + 17, 3)
+    x = signals.mixed((nframes + 1) * 16129 + 17, 3)  # (a frame is sent when the next one is complete, like the reference's)
     fin = str(tmp_path / "in.bin")
     x.tofile(fin)
     port = _free_port()
