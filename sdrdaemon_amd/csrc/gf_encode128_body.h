@@ -112,7 +112,22 @@ __device__ __forceinline__ void gf_encode128_wg(const Enc128Args &a, int bx, uns
     const size_t frc = live ? (size_t)fr : 0;
     const unsigned *src = reinterpret_cast<const unsigned *>(a.in + frc * a.in_frame_bytes) + 1 + (live ? col : 0);
     unsigned *dst = reinterpret_cast<unsigned *>(a.out + frc * a.out_frame_bytes) + 1 + (live ? col : 0);
-    const unsigned hdr0 = (live && col == 0) ? src[-1] : 0u;
+    // block 0 of the frame (header + meta block): from memory, or (K2 runs in this very launch) derived like K2 derives it
+    unsigned hdr0 = 0u, blk0 = 0u;
+    bool own0 = false;
+    if (a.meta_count > 0 && a.gen_done > 0) {
+        const int f = fr % a.gen_cap, fi = f - a.meta_first;
+        if (fr >= 0 && fi >= 0 && fi < a.meta_count) { // (workgroup-uniform: the shuffle inside frame_meta_words sees whole waves)
+            unsigned w[6];
+            frame_meta_words(a.meta_w, a.meta_idx0, a.meta_rate, fi, w);
+            own0 = true;
+            hdr0 = (a.meta_frame_count0 + (unsigned)fi) & 0xffffu;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (col == k) blk0 = w[k];
+        }
+    }
+    if (!own0) hdr0 = (live && col == 0) ? src[-1] : 0u;
     // fused framing: blocks 1..127 of this frame come straight from the decimated stream (127 samples each)
     bool fused = false;
     const unsigned *bsrc = src; // block b at bsrc[b * bstride]
@@ -126,6 +141,13 @@ __device__ __forceinline__ void gf_encode128_wg(const Enc128Args &a, int bx, uns
         }
     }
     unsigned *fdst = const_cast<unsigned *>(src);
+    // the frame that was open when the call began: its first lin_pending samples are in the frame area, the rest comes now
+    bool strad = false;
+    const unsigned *linp = nullptr;
+    if (a.lin && live && a.lin_straddle && !fused) {
+        const int s = fr / a.lin_cap, f = fr - s * a.lin_cap;
+        if (f == 0) { strad = true; linp = a.lin + (size_t)s * a.lin_stride; }
+    }
 
     const int npairs = (a.rows + 31) / 32; // pairs of 16-row tiles
 #pragma unroll 1
@@ -138,9 +160,22 @@ __device__ __forceinline__ void gf_encode128_wg(const Enc128Args &a, int bx, uns
         for (int q = 0; q < 2; ++q) {
             const int cb = 2 * w + q;
             unsigned v[2 * KN - 1];
-            if (live) {
+            if (live && strad) {
+#pragma unroll
+                for (int i = 0; i < KN; ++i) {
+                    const int b = KN * cb + i;
+                    if (b == 0) { v[i] = src[0]; continue; }
+                    const int wi = (b - 1) * 127 + col;
+                    if (wi < a.lin_pending) {
+                        v[i] = src[(size_t)b * 128];
+                    } else {
+                        v[i] = linp[wi - a.lin_pending];
+                        if (tp == 0) fdst[(size_t)b * 128] = v[i];
+                    }
+                }
+            } else if (live) {
                 // (block 0 = the meta block is never in the stream)
-                v[0] = (fused && cb == 0) ? src[0] : bsrc[(size_t)(KN * cb) * bstride];
+                v[0] = cb == 0 ? (own0 ? blk0 : src[0]) : bsrc[(size_t)(KN * cb) * bstride];
 #pragma unroll
                 for (int i = 1; i < KN; ++i) v[i] = bsrc[(size_t)(KN * cb + i) * bstride];
                 if (fused && tp == 0) {

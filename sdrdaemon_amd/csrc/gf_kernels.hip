@@ -149,6 +149,23 @@ __global__ __launch_bounds__(GF_NT, 4) void gf_encode128_kernel(Enc128Args a) //
     gf_encode128_wg(a, (int)blockIdx.x, ldsraw);
 }
 
+// The Rx pipe's last launch: the encoder's workgroups and, behind them, K2's (the frames left open at either end of the call,
+// meta blocks, headers).  One launch instead of two: K2 used to run first because the encoder reads what K2 writes (block 0 of
+// the frames the call starts, the tail of the frame the call completes); now the encoder derives / fetches both itself
+// (Enc128Args::meta_*, lin_straddle), so the two roles touch disjoint bytes (the encoder's write-back of block 0 repeats K2's).
+#include "frame_pack_body.h"
+__global__ __launch_bounds__(GF_NT, 4) void gf_encode128_pack_kernel(Enc128Args a, FrameArgs f, unsigned pack_bx)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ldsraw[ENC128_LDS_BYTES];
+    const unsigned nenc = 2u * (unsigned)a.nlist;
+    if (blockIdx.x < nenc) {
+        gf_encode128_wg(a, (int)blockIdx.x, ldsraw);
+    } else {
+        const unsigned u = blockIdx.x - nenc;
+        frame_pack_wg(f, (int)(u / pack_bx), u % pack_bx, pack_bx);
+    }
+}
+
 // scatter copy of 508-byte blocks: dst[f][map[f][p]] = src[f][p] for map >= 0
 __global__ void block_scatter_kernel(const uint8_t *src, size_t src_frame_bytes, int src_pitch, int src_off, uint8_t *dst,
                                      size_t dst_frame_bytes, int dst_pitch, int dst_off, const int16_t *map, int nblocks,
@@ -624,6 +641,16 @@ hipError_t launch_gf_encode128(const Enc128Args &a, hipStream_t stream)
 {
     if (a.nlist <= 0 || a.rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(gf_encode128_kernel, dim3(2 * a.nlist), dim3(GF_NT), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gf_encode128_pack(const Enc128Args &a, const FrameArgs &f, int nstreams, hipStream_t stream)
+{
+    size_t blocks = (f.n - (f.skip_to - f.skip_from) + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    const unsigned nenc = a.rows > 0 ? 2u * (unsigned)(a.nlist > 0 ? a.nlist : 0) : 0u;
+    hipLaunchKernelGGL(gf_encode128_pack_kernel, dim3(nenc + (unsigned)blocks * (unsigned)nstreams), dim3(GF_NT), 0, stream, a, f, (unsigned)blocks);
     return hipGetLastError();
 }
 

@@ -233,10 +233,22 @@ struct Enc128Args {
     const unsigned *lin;
     size_t lin_stride;              // dwords between streams
     int lin_cap, lin_first, lin_pending;
+    int lin_straddle;               // 1: frame slot 0 (open when the call began, lin_pending samples in it) is completed from
+                                    // lin[0 ..] by the encoder itself, K2 leaves it alone (launch_gf_encode128_pack)
+    // Rx pipe with K2 in the SAME launch (launch_gf_encode128_pack): the meta blocks and frame indices of the frame slots
+    // meta_first .. meta_first + meta_count - 1 of every stream (gen_* addressing) are not in memory yet when the encoder reads
+    // block 0: it derives them itself, exactly as K2 writes them (frame_meta_words).  meta_count = 0: everything is in memory.
+    int meta_first, meta_count;
+    unsigned meta_frame_count0;
+    unsigned meta_w[6];
+    uint64_t meta_idx0;
+    unsigned meta_rate;
 };
 // smallest number of recovery blocks the structured 128-original encoder is used for (below: the generic matrix kernel)
 constexpr int ENC128_MIN_ROWS = 13;
 hipError_t launch_gf_encode128(const Enc128Args &a, hipStream_t stream);
+// encoder + K2 (framing residue: open frames, meta blocks, headers) of the same call in one launch
+hipError_t launch_gf_encode128_pack(const Enc128Args &a, const FrameArgs &f, int nstreams, hipStream_t stream);
 hipError_t launch_block_scatter(const uint8_t *src, size_t src_frame_bytes, int src_pitch, int src_off, uint8_t *dst,
                                 size_t dst_frame_bytes, int dst_pitch, int dst_off, const int16_t *map, int nblocks, int nframes,
                                 hipStream_t stream);

@@ -429,7 +429,9 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
 
     size_t n_out = 0;
     EncodeLin elin;
-    bool use_lin = false;
+    bool use_lin = false, pack_with_encoder = false;
+    FrameArgs fa;
+    memset(&fa, 0, sizeof(fa));
     const bool structured = R >= ENC128_MIN_ROWS && frame_bytes % 4 == 0; // gf_encode128_kernel serves this setting
     const bool filterless = L == 0 || (rx->cfg.fcpos != SDRHIP_FC_CEN && L <= 2); // Decimators.cpp:22-91,127-170: no cascade kernel
     const Enc128Args *fuse = rx->late.encode && c->opt.rx_fused ? &rx->late.k : nullptr;
@@ -454,8 +456,6 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
                 use_lin = true;
             }
         }
-        FrameArgs fa;
-        memset(&fa, 0, sizeof(fa));
         if (use_lin) {
             fa.skip_from = (size_t)elin.first * SDRHIP_SAMPLES_PER_FRAME - (size_t)elin.pending;
             fa.skip_to = done * SDRHIP_SAMPLES_PER_FRAME - (size_t)elin.pending;
@@ -466,8 +466,13 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         fa.meta_first = meta.first; fa.meta_count = meta.count; fa.meta_frame_count0 = meta.frame_count0;
         memcpy(fa.meta_w, meta.w, sizeof(fa.meta_w));
         fa.meta_idx0 = meta.idx0; fa.meta_rate = meta.rate;
-        hipError_t e = launch_frame_pack(fa, S, c->stream);
-        if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "frame pack launch: %s", hipGetErrorString(e));
+        // K2 rides in the encoder's launch when this call's frames are encoded right away by the structured encoder (one launch
+        // less per step); otherwise it goes out now
+        pack_with_encoder = !rx->pipelined && c->opt.rx_fused && structured && R > 0 && use_lin;
+        if (!pack_with_encoder) {
+            hipError_t e = launch_frame_pack(fa, S, c->stream);
+            if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "frame pack launch: %s", hipGetErrorString(e));
+        }
     } else {
         // ---- decimate straight into the frame layout (VALU cascade kernel with the framing epilogue)
         rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, reinterpret_cast<int16_t *>(work), stream_bytes / 4, &n_out, 1,
@@ -488,8 +493,22 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
             k.rows = R; k.nframes = (int)((size_t)S * rx->cap_frames);
             k.nlist = (int)((size_t)S * done); k.gen_done = (int)done; k.gen_cap = (int)rx->cap_frames;
             if (use_lin) { k.lin = elin.lin; k.lin_stride = elin.stride; k.lin_cap = elin.cap; k.lin_first = elin.first; k.lin_pending = elin.pending; }
-            if (rx->pipelined) encode_later = true; // rides in the next call's decimator launch (or sdrhip_rx_flush)
-            else if ((rc = fec_encode128_launch(c, k))) return rc;
+            if (rx->pipelined) {
+                encode_later = true; // rides in the next call's decimator launch (or sdrhip_rx_flush)
+            } else if (pack_with_encoder) {
+                // encoder + K2 in one launch: the encoder derives the meta blocks of the frames this call starts itself and
+                // completes the frame that was open (its tail comes from the stream-order buffer), K2 leaves both alone
+                k.meta_first = meta.first; k.meta_count = meta.count; k.meta_frame_count0 = meta.frame_count0;
+                memcpy(k.meta_w, meta.w, sizeof(k.meta_w));
+                k.meta_idx0 = meta.idx0; k.meta_rate = meta.rate;
+                if (elin.first == 1) { k.lin_straddle = 1; fa.skip_from = 0; }
+                hipError_t e;
+                {
+                    KTimer kt(c, SDRHIP_K_FEC_ENCODE);
+                    e = launch_gf_encode128_pack(k, fa, S, c->stream);
+                }
+                if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "encode + frame pack launch: %s", hipGetErrorString(e));
+            } else if ((rc = fec_encode128_launch(c, k))) return rc;
         } else {
             // generic matrix kernel: one launch for every stream, frame list in groups of GF_FRAMES_PER_GROUP
             if (rx->flist_done != done || rx->flist_cap != rx->cap_frames) {
