@@ -139,6 +139,7 @@ struct MfOut {
     unsigned *dump;       // 16 bytes per lane that swallow the stores of the warm-up period (no branch in the loop body)
     int store;            // 0 during warm-up
     int norm, trunk;
+    unsigned *wc;         // (MF_ABL 4096 experiment)
     unsigned hold[4];     // the packed outputs of the even tile of a pair (stores go out as full 128-byte lines, see mf_stage)
 };
 
@@ -284,6 +285,10 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
 #if MF_ABL & 2048 // (timing experiment: every store goes to the dump slot)
         dst = oc.dump;
 #endif
+#if MF_ABL & 4096 // (timing experiment, wrong layout: a wave's stores are contiguous, 1 KiB per instruction)
+        dst = oc.store ? oc.wc : oc.dump;
+        oc.wc += oc.store ? 128 : 0;
+#endif
 #if MF_ABL & 128 // no global stores
         asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(dst));
 #elif defined(MF_STV) // store experiments: 1 = only the I lane of a pair stores, 2 = non-temporal, 3 = both
@@ -387,7 +392,7 @@ template <int SLOT, int D> __device__ __forceinline__ void mf_dma_issue(unsigned
 #ifndef MF_LOADER
 #define MF_LOADER 0 // measured (tools/exp16.sh, 5 interleaved rounds): 0.244-0.252 ms against 0.232-0.238 ms with the DMAs in the compute waves
 #endif
-constexpr int MF_NT5 = 320; // threads of a matrix-core workgroup with a loader wave
+constexpr int MF_NT5 = 256 + 64 * (MF_LOADER > 0 ? MF_LOADER : 1); // threads of a matrix-core workgroup with its loader wave(s)
 
 __device__ __forceinline__ void mf_dma_issue_rt(unsigned m0v, unsigned voff, unsigned long long span_base)
 {
@@ -395,7 +400,9 @@ __device__ __forceinline__ void mf_dma_issue_rt(unsigned m0v, unsigned voff, uns
 }
 
 // ngroups = groups of 8 steps every compute wave of the launch walks (4 per period)
-__device__ __forceinline__ void mf_loader(const DecimArgs &a, int bx, unsigned lds_addr, size_t W, int ngroups)
+// MF_LOADER = number of loader waves per workgroup (1, 2 or 4): loader j feeds the compute waves j * 4 / MF_LOADER .. of its
+// workgroup (NW of them).  One loader holds at most 64 requests in flight (6-bit vmcnt): ~25-30 GB/s per CU, the whole kernel's need.
+__device__ __forceinline__ void mf_loader(const DecimArgs &a, int bx, unsigned lds_addr, size_t W, int ngroups, int w0, int NW)
 {
     const int lane = threadIdx.x & 63;
     const int total = a.nstreams * a.mf_wps;
@@ -404,8 +411,8 @@ __device__ __forceinline__ void mf_loader(const DecimArgs &a, int bx, unsigned l
     int live = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const int gw = bx * 4 + w;
-        if (gw < total) {
+        const int gw = bx * 4 + w0 + w;
+        if (w < NW && gw < total) {
             const int stream = gw / a.mf_wps, ws = gw - stream * a.mf_wps;
             base[w] = (unsigned long long)(reinterpret_cast<const char *>(a.in) + ((size_t)stream * a.in_stride + a.mf_head + (size_t)ws * 8 * S - W) * 4);
             live = w + 1;
@@ -413,9 +420,9 @@ __device__ __forceinline__ void mf_loader(const DecimArgs &a, int bx, unsigned l
             base[w] = 0;
         }
     }
-    const unsigned ring0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    const unsigned ring0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr + (unsigned)w0 * MF_WAVE_RING));
     const unsigned long long sstep = (unsigned long long)S * 4;
-    auto issue_group = [&](int g) { // the 8 DMAs of group g of every live compute wave
+    auto issue_group = [&](int g) { // the 8 DMAs of group g of every live compute wave of this loader
         const unsigned voff = 16u * (unsigned)lane + 1024u * (unsigned)g;
         const unsigned slot = ring0 + (unsigned)(g & 3) * MF_GROUP_BYTES;
         for (int w = 0; w < live; ++w) {
@@ -428,15 +435,21 @@ __device__ __forceinline__ void mf_loader(const DecimArgs &a, int bx, unsigned l
             }
         }
     };
+    // "group g has landed": 2 x 8 x NW DMAs (groups g + 1, g + 2) may still be in flight behind its last one (the counter
+    // holds 63 at most: with four waves per loader one more DMA is awaited)
+    auto wait_two_groups = [&]() {
+        if (live < NW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a partly filled workgroup: fewer DMAs per group)
+        else if (NW == 4) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        else if (NW == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    };
     issue_group(0); issue_group(1); issue_group(2);
-    // barrier 0: group 0 has landed (64 DMAs at most were issued after its last one; the counter holds 63: one more is awaited)
-    asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-    if (live < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(0) : "memory"); // (fewer DMAs per group: the count above is for four waves)
+    wait_two_groups(); // barrier 0: group 0 has landed
     __builtin_amdgcn_s_barrier();
     for (int r = 0; r + 1 < ngroups; ++r) {
         if (r + 3 < ngroups) issue_group(r + 3);
         // group r + 1 must have landed before barrier r + 1
-        if (r + 3 < ngroups && live == 4) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        if (r + 3 < ngroups) wait_two_groups();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -592,6 +605,7 @@ template <int NS, bool DMA = true> __device__ __forceinline__ void mf_wave(const
         unsigned *obase = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
         const size_t first = ((wave_start + (size_t)p * S) >> L) + 4u * (unsigned)q; // this lane's first output
         oc.p = obase + first;
+        oc.wc = obase + (wave_start >> L) + 4u * (unsigned)(p + 8 * q);
     }
 
     MfState<NS> st;
@@ -679,11 +693,13 @@ template <int L, bool PACK16> __global__ __launch_bounds__(mf_block_threads(L), 
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
     const int bx = blockIdx.x;
     if constexpr (mf_loader_applies(L)) {
-        if (threadIdx.x >= NT) { // the fifth wave: loader of a matrix-core workgroup, nothing to do in a VALU piece
+        if (threadIdx.x >= NT) { // a loader wave of a matrix-core workgroup; nothing to do in a VALU piece
             if (bx < nmf) {
                 constexpr size_t W = (size_t)64 << L;
+                constexpr int NW = 4 / (MF_LOADER > 0 ? MF_LOADER : 1);
                 const int nper = (int)((W + a.mf_span) / 32) / mf_period<L>();
-                mf_loader(a, bx, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds, W, 4 * nper);
+                const int j = __builtin_amdgcn_readfirstlane((int)((threadIdx.x - NT) >> 6));
+                mf_loader(a, bx, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds, W, 4 * nper, j * NW, NW);
             }
             return;
         }

@@ -50,6 +50,7 @@ while time.time() - t0 < budget:
     ctx.set_option("decim_path", str(rs.choice(["auto", "valu", "mfma", "mfma"])))
     ctx.set_option("mfma_span", 1024 * int(rs.choice([1, 1, 2, 3, 5, 16])))
     ctx.set_option("rx_fused", int(rs.randint(0, 2)))
+    ctx.set_option("dec_path", str(rs.choice(["syndrome", "syndrome", "dense"])))
     if what == "decim":
         S = int(rs.randint(1, 4))
         bias = int(rs.randint(0, 2))
@@ -103,12 +104,26 @@ while time.time() - t0 < budget:
         fc = int(rs.randint(0, 3))  # (decim 0 and inf / sup 1-2 are the filter-less settings framed by K2)
         R = int(rs.choice([0, 1, 7, 13, 32, 100]))
         bias = int(rs.randint(0, 2))
-        rx = sd.RxPipe(ctx, S, log2decim=L, fcpos=fc, hb_variant=bias, nb_fec=R)
+        pipelined = bool(rs.rand() < 0.4)  # frames one call late (the encoder rides in the next call's decimator launch) + flush
+        rx = sd.RxPipe(ctx, S, log2decim=L, fcpos=fc, hb_variant=bias, nb_fec=R, pipelined=pipelined)
+        waiting = None  # pipelined: what the NEXT call (or the flush) has to deliver: (expected frames per stream, R)
+
+        def check(got, exp, Rexp, tag):
+            for s in range(S):
+                assert got.shape[1] == exp[s].shape[0], ("rx count",) + tag + (s,)
+                for f in range(exp[s].shape[0]):
+                    assert np.array_equal(got[s, f, :128], exp[s][f]), ("rx frame",) + tag + (s, f)
+                    if Rexp:
+                        assert np.array_equal(got[s, f, 128:], orc.frame_encode(exp[s][f], Rexp)), ("rx fec",) + tag + (s, f)
+
         ods = [orc.decimators(bias) for _ in range(S)]
         frs = [orc.framer(nb_fec_blocks=R) for _ in range(S)]
         dev_rate = 625000 << L  # the pipe is created with the sink rate 625000: the device runs at 625000 * 2^decim
         for k in range(int(rs.randint(1, 6))):
             if k and rs.rand() < 0.3:  # control message between batches
+                if pipelined and waiting is not None:  # (the slots change size with fecblk: deliver what waits first)
+                    check(rx.flush().reshape(S, -1, 128 + waiting[1], 512), waiting[0], waiting[1], (it, k, "flush"))
+                    waiting = None
                 L = int(rs.randint(0, 5))
                 fc = int(rs.randint(0, 3))
                 R = int(rs.choice([0, 1, 7, 13, 32, 100]))
@@ -127,16 +142,22 @@ while time.time() - t0 < budget:
                 got = rx.process_view(xt[:, :n_raw], tv_sec=k, tv_usec=it).torch().cpu().numpy().reshape(S, -1, 128 + R, 512)
             else:
                 got = rx.process(x, tv_sec=k, tv_usec=it).reshape(S, -1, 128 + R, 512)
+            exp = []
             for s in range(S):
                 y, ss = ods[s].decimate(L, fc, 16, x[s])
                 frs[s].s.sample_bytes, frs[s].s.sample_bits = (ss - 1) // 8 + 1, ss
                 frs[s].s.tv_sec, frs[s].s.tv_usec = k, it
-                e = frs[s].write(y)
-                assert got.shape[1] == e.shape[0], ("rx count", it, k, s)
-                for f in range(e.shape[0]):
-                    assert np.array_equal(got[s, f, :128], e[f]), ("rx frame", it, k, s, f)
-                    if R:
-                        assert np.array_equal(got[s, f, 128:], orc.frame_encode(e[f], R)), ("rx fec", it, k, s, f)
+                exp.append(frs[s].write(y))
+            if not pipelined:
+                check(got, exp, R, (it, k))
+            else:
+                if waiting is not None:
+                    check(got, waiting[0], waiting[1], (it, k, "late"))
+                else:
+                    assert got.shape[1] == 0, ("rx pipelined first", it, k)
+                waiting = (exp, R) if exp[0].shape[0] else None
+        if pipelined and waiting is not None:
+            check(rx.flush().reshape(S, -1, 128 + waiting[1], 512), waiting[0], waiting[1], (it, "end"))
     elif what == "fec":
         # generic CM256 geometry through the single-call ABI: encode, lose blocks, decode in place
         k = int(rs.randint(1, 201))
