@@ -79,6 +79,8 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
 {
     if (nframes == 0) return SDRHIP_OK;
     if (nframes > 0x3fffffffu) return fail(SDRHIP_EINVAL, "fec decode: too many frames in one call");
+    // (the dense path's scatter pass puts the frame index in gridDim.y: 65535 at most; the default syndrome path has no such pass)
+    if (!c->opt.dec_syndrome && nframes > 65535) return fail(SDRHIP_EINVAL, "fec decode (dec_path = dense): at most 65535 frames per call");
     int rc;
     if ((rc = c->dec_plan.reserve(DecodeBuffers::bytes(nframes)))) return rc;
     DecodeBuffers d;
