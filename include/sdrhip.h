@@ -241,7 +241,8 @@ size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in);
  * (frames_out, *n_frames, sdrhip_rx_frames_view) the frames that the PREVIOUS call completed; their recovery blocks are computed
  * by encoder workgroups that ride in this call's decimator launch (one launch instead of two, the encoder fills the issue
  * slots the decimator's waves leave empty).  Same bytes, one call later.  sdrhip_rx_flush encodes and delivers the frames the
- * last call completed (end of stream, before switching the mode off).  frames_out of a pipelined call must hold
+ * last call completed (end of stream, before switching the mode off, and before a sdrhip_rx_reconfigure that changes fecblk:
+ * the waiting frames carry the old frame size; reconfigure refuses otherwise).  frames_out of a pipelined call must hold
  * sdrhip_rx_max_frames() frames per stream. */
 int sdrhip_rx_set_pipelined(sdrhip_rx *rx, int on);
 int sdrhip_rx_flush(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames, int mem);

@@ -221,9 +221,12 @@ extern "C" int sdrhip_rx_reconfigure(sdrhip_rx *rx, const sdrhip_rx_config *cfg)
     if (cfg->hb_variant != rx->cfg.hb_variant) return fail(SDRHIP_EINVAL, "rx_reconfigure: hb_variant is fixed at creation");
     sdrhip_ctx *c = rx->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    if (cfg->nb_fec != rx->cfg.nb_fec && rx->late.have)
+        return fail(SDRHIP_EINVAL, "rx_reconfigure: frames of the previous call wait for delivery (pipelined mode): sdrhip_rx_flush them "
+                                   "before changing fecblk (they carry the old frame size)");
     if (cfg->nb_fec != rx->cfg.nb_fec && rx->cap_frames) {
         // the slots change size: the frame being filled (its 128 original super blocks) moves to slot 0 of a new area
-        if ((rc = rx_settle(rx))) return rc; // (frames waiting for delivery are encoded with the value they completed under)
+        if ((rc = rx_settle(rx))) return rc;
         const int S = rx->nstreams;
         const size_t old_fb = (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
         const size_t new_fb = (size_t)(SDRHIP_NB_ORIGINAL + cfg->nb_fec) * SDRHIP_UDPSIZE;

@@ -228,3 +228,19 @@ def test_pipelined_equals_unpipelined_ragged(ctx, oracle, cfg):
     finally:
         ctx.set_option("decim_path", "auto")
         ctx.set_option("mfma_span", 0)
+
+
+def test_pipelined_reconfigure_needs_a_flush(ctx):
+    """frames that wait for delivery carry the old frame size: a fecblk change is refused until they are flushed"""
+    import sdrdaemon_amd as sd
+
+    x = signals.noise(3 * 16129 * 16, 5)
+    rx = sd.RxPipe(ctx, 1, log2decim=4, nb_fec=32, pipelined=True)
+    assert rx.process(x[:2 * 16129 * 16], 1, 2).shape[0] == 0
+    with pytest.raises(sd.SdrHipError):
+        rx.reconfigure(nb_fec=8)
+    assert rx.flush().shape[1] == 2
+    rx.reconfigure(nb_fec=8)
+    rx.process(x[2 * 16129 * 16:], 3, 4)
+    out = rx.flush()
+    assert out.shape[1:] == (1, 136, 512)
