@@ -504,8 +504,9 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
     const __attribute__((address_space(3))) char *lrd =
         (const __attribute__((address_space(3))) char *)(size_t)(ring + 16u * (unsigned)(mf_block_units(0) + 72 * p + 2 * (p >> 2) + (MF_FRONT2 ? 0 : 4 * comp) + q));
     unsigned voff[4];
+    const unsigned vmax = 16u * (unsigned)lane + 1024u * (unsigned)(4 * nper - 1); // offset of the wave's last group
 #pragma unroll
-    for (int g = 0; g < 4; ++g) voff[g] = 16u * (unsigned)lane + 1024u * (unsigned)(g == 3 ? 3 : g + 4);
+    for (int g = 0; g < 4; ++g) voff[g] = min(16u * (unsigned)lane + 1024u * (unsigned)(g == 3 ? 3 : g + 4), vmax);
     {
         // groups 0, 1, 2 of the ring
         unsigned v0 = 16u * (unsigned)lane;
@@ -538,7 +539,13 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
 #if !(MF_ABL & 512) // (timing experiment: no DMAs in the loop)
             mf_dma_issue<g, i % 8>(ring, voff[g], sb[i % 8]);
 #endif
+            // (next period's group of this slot; past the wave's last group the DMAs re-read that last group -- cache hits, no
+            // HBM traffic, and the vmcnt arithmetic stays as it is)
+#ifdef MF_NOCLAMP // (A / B)
             if constexpr (i % 8 == 7) voff[g] += 4096u;
+#else
+            if constexpr (i % 8 == 7) voff[g] = min(voff[g] + 4096u, vmax);
+#endif
 #if MF_ABL & 16
             asm volatile("" : "+v"(st.O[0][0]), "+v"(st.O[0][1]) : "v"(r));
 #elif MF_FRONT2
@@ -867,8 +874,8 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
     if (wps == 0 || wps > 0x7fffffffu / (size_t)nstreams) return false;
     if (8 * S * 4 >= 0xffffffffu) return false;   // lane offsets inside a wave are 32 bits
     size_t tail_start = head + wps * 8 * S;
-    // the waves read past their last span: 8 steps of register prefetch (256 samples) or three groups of the LDS-DMA ring (768)
-    if (n_used - tail_start < (mf_dma_applies(log2decim) ? 1024u : 256u)) {
+    // the register-ring waves read up to 8 steps (256 samples) past their last span (the LDS-DMA ring clamps its run-ahead)
+    if (n_used - tail_start < 256u) {
         if (--wps == 0) return false;
         tail_start = head + wps * 8 * S;
     }
