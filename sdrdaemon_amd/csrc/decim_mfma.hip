@@ -329,7 +329,7 @@ template <int NS, int I> __device__ __forceinline__ void mf_front(MfState<NS> &s
 // second half rB; the same addresses: an LDS broadcast) and pick their own component -- no exchange with the neighbour (2 DPP moves
 // and 2 v_perm less per step: VALU issue is what bounds the kernel; the second ds_read_b128 issues on the LDS port).
 #ifndef MF_FRONT2
-#define MF_FRONT2 0 // measured (tools/exp25.sh, 4 interleaved rounds): 0.2359-0.2381 ms with it, 0.2356-0.2412 without: 4 VALU fewer per step
+#define MF_FRONT2 0 // measured (tools/experiments_r03/exp25.sh, 4 interleaved rounds): 0.2359-0.2381 ms with it, 0.2356-0.2412 without: 4 VALU fewer per step
                     // change nothing -- with the DMA ring the kernel sits on its memory skeleton (0.225 ms with its stores), not on VALU issue
 #endif
 template <int NS, int I> __device__ __forceinline__ void mf_front2(MfState<NS> &st, const MfConst &k, MfFront &f, const uint4_t rA, const uint4_t rB)
@@ -363,7 +363,7 @@ template <int NS, int I> __device__ __forceinline__ void mf_front2(MfState<NS> &
 #endif
 constexpr int MF_GROUP_BYTES = 9216;             // 8 blocks of 1 KiB + their skew
 constexpr int MF_WAVE_RING = 4 * MF_GROUP_BYTES; // bytes of LDS per wave
-// decimate16 only: measured with 3 interleaved rounds (tools/exp24.sh), register ring against LDS-DMA ring: decimate16 0.2445 / 0.2363 ms,
+// decimate16 only: measured with 3 interleaved rounds (tools/experiments_r03/exp24.sh), register ring against LDS-DMA ring: decimate16 0.2445 / 0.2363 ms,
 // decimate32 0.2512 / 0.2537, decimate64 0.2693 / 0.2947 (their warm-up and the ring's run-ahead past the span grow with the ratio)
 __host__ __device__ constexpr bool mf_dma_applies(int ns) { return MF_DMA && ns == 4; } // (period of 32 steps; one workgroup per CU)
 __host__ __device__ constexpr int mf_block_units(int p) { return 72 * p + 2 * (p >> 2); }
@@ -390,7 +390,7 @@ template <int SLOT, int D> __device__ __forceinline__ void mf_dma_issue(unsigned
 // it the compute waves start group k + 1.  The four compute waves run the same instruction stream on their own SIMDs, the
 // loader shares SIMD 0 with one of them and issues on other ports (scalar / vector memory).
 #ifndef MF_LOADER
-#define MF_LOADER 0 // measured (tools/exp16.sh, 5 interleaved rounds): 0.244-0.252 ms against 0.232-0.238 ms with the DMAs in the compute waves
+#define MF_LOADER 0 // measured (tools/experiments_r03/exp16.sh, 5 interleaved rounds): 0.244-0.252 ms against 0.232-0.238 ms with the DMAs in the compute waves
 #endif
 constexpr int MF_NT5 = 256 + 64 * (MF_LOADER > 0 ? MF_LOADER : 1); // threads of a matrix-core workgroup with its loader wave(s)
 
