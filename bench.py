@@ -2,7 +2,8 @@
 """bench.py -- headline metric of BASELINE.json on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or as the
+     plain command above: without WORLD_SIZE in the environment it launches the N ranks itself)
 
 Workload (config.workload): BASELINE.json configs[2] -- TestSource-shaped 16-bit IQ streams,
 decimate by 16 centred (Decimators::decimate16_cen over IntHalfbandFilterEO1) + UDPSinkFEC
@@ -13,8 +14,9 @@ A step = one sdrhip_rx_process() call over that batch (decimate -> frame -> enco
 streams are continuous across steps (filter state and partial frames carry over).
 
 --streams N fixes the TOTAL number of streams of the job (the same 64 streams at
-1 / 2 / 4 / 8 GPUs, stream s on rank s mod G): "scaling" is then "strong"; without it every rank
-owns 8 streams ("weak").  At N = 1 the line also carries `configs`: the other single-GPU
+2 / 4 / 8 GPUs, stream s on rank s mod G): "scaling" is then "strong"; that is the default for
+--gpus > 1 (64 streams = configs[4]); --streams 0 gives every rank 8 streams ("weak"), which is
+also what the one-GPU headline run does.  At N = 1 the line also carries `configs`: the other single-GPU
 configurations of BASELINE.json measured in the same run (configs[1] decimate16_cen alone,
 configs[2] as ONE stream of 2^27 samples, configs[3] the Tx pipe with a different random
 24-erasure pattern in every frame), each with its own roofline object.
@@ -75,8 +77,6 @@ def make_input(ctx, device, n, seeds, kind):
 
 def decim_kernel_name(plan):
     """the kernel the library actually launched for decimate16_cen (sdrhip_decimators_last_plan / sdrhip_rx_last_plan)"""
-    if plan.get("fused"):
-        return "rx_fused_kernel<4,true>"
     return {"valu": "decim_kernel<4,2,true>", "mfma": "decim_mfma_kernel<4,true>"}.get(plan["path"], "none")
 
 
@@ -253,28 +253,78 @@ def extra_configs(ctx, dev, x, kind):
                 "ms_per_step": round(wall, 4), "value": round(n1 / wall / 1e3, 1), "unit": "Msamples/s (input)",
                 "roofline": roof(BYTES_DECIM * n1, per[K_DECIMATE], decim_kernel_name(rx1.last_plan()))})
     del x1, rx1
-    # configs[3]: Tx pipe, 128+32 frames with 24 of the 160 blocks lost, a DIFFERENT random pattern in every frame,
-    # frames resident on the device (block indices read from the headers by the planning kernel), interpolate by 16
-    F, Stx = 128, 8
-    g = torch.Generator(device=dev).manual_seed(77)
-    frames = torch.randint(0, 256, (Stx * F, 128, 512), generator=g, device=dev, dtype=torch.uint8)
-    frames[:, :, 2] = torch.arange(128, device=dev, dtype=torch.uint8)
-    allb = torch.cat([frames, sd.fec_encode_frames(ctx, frames, NB_FEC)], dim=1)
-    rs = np.random.RandomState(3)
-    keep = np.stack([np.sort(rs.permutation(160)[:136])[:128] for _ in range(Stx * F)])
-    rxf = allb[torch.arange(Stx * F, device=dev)[:, None], torch.from_numpy(keep).to(dev)].contiguous().reshape(Stx, F, 128, 512)
-    tx = sd.TxPipe(ctx, Stx, LOG2DECIM)
+    # configs[3]: Tx pipe.  The received frames are config 3's OUTPUT: the first 128 frames of every stream of this very bank
+    # through the Rx pipe, 24 of each frame's 160 blocks lost (a DIFFERENT random set in every frame, tests/headline_inputs.py),
+    # frames resident on the device (block indices read from the headers by the planning kernel), decode + interpolate by 16.
+    import headline_inputs as hi
+
+    meta = {"tv_sec": 1, "tv_usec": 0, "center_frequency_khz": 435000, "sample_rate": 625000, "nb_fec": NB_FEC}
+    rxf, keep = hi.tx_received_frames(ctx, x, meta)
+    Stx, F = rxf.shape[0], rxf.shape[1]
+    tx = sd.TxPipe(ctx, Stx, hi.TX_LOG2_INTERP)
     ctx.set_option("dec_max_rows", NB_FEC)  # the sender's fecblk (it is in every frame's meta block): no frame carries more recovery blocks
-    wall, per = timed_steps(ctx, lambda: tx.process(rxf), [K_FEC_DECODE, K_INTERPOLATE])
-    ctx.set_option("dec_max_rows", 128)
-    nout = Stx * F * 16129 << LOG2DECIM
-    out.append({"config": "configs[3]: %d streams x %d frames per step, UDPSourceFEC decode 128+32 with 24 erased blocks (a distinct random "
-                          "pattern per frame, %d distinct) + interpolate16_cen" % (Stx, F, len({k.tobytes() for k in keep})),
+    try:
+        wall, per = timed_steps(ctx, lambda: tx.process(rxf), [K_FEC_DECODE, K_INTERPOLATE])
+        del tx
+        tx_verified = verify_tx_step(ctx, rxf, kind, n)
+    finally:
+        ctx.set_option("dec_max_rows", 128)
+    nout = Stx * F * 16129 << hi.TX_LOG2_INTERP
+    out.append({"config": "configs[3]: %d streams x %d frames per step (config 3's frames of this bank), UDPSourceFEC decode 128+32 with 24 erased "
+                          "blocks (a distinct random pattern per frame, %d distinct) + interpolate16_cen" % (Stx, F, len({k.tobytes() for k in keep})),
                 "ms_per_step": round(wall, 4), "value": round(nout / wall / 1e3, 1), "unit": "Msamples/s (output)",
                 "decode_ms_per_step": round(per[K_FEC_DECODE], 4),
-                "roofline": roof((4.0 + 4.0 / 16.0) * nout, per[K_INTERPOLATE], "interp_kernel<4>"),
-                "pipe_gbps_config4": round((4.0 + 128.0 * 512.0 / 258064.0) * nout / (wall * 1e-3) / 1e9, 1)})
+                "roofline": roof((4.0 + 4.0 / 16.0) * nout, per[K_INTERPOLATE], interp_kernel_name(ctx)),
+                "pipe_gbps_config4": round((4.0 + 128.0 * 512.0 / 258064.0) * nout / (wall * 1e-3) / 1e9, 1),
+                "verified": tx_verified})
     return out
+
+
+def interp_kernel_name(ctx):
+    return "interp_kernel<4>"
+
+
+def verify_tx_step(ctx, rxf, kind, n):
+    """Behind the timed Tx region: the SAME call (dec_max_rows still at the sender's fecblk) on a fresh handle, whole-output
+    digests per stream.  With the default `hash` input and bench.py's own geometry the expected digests are the committed ones
+    (tests/golden/headline_golden.json "tx_bank8": oracle cm256_decode + the compiled reference's interpolate16_cen); otherwise
+    the output must equal that of the dense decoder path of this library."""
+    import hashlib
+
+    import sdrdaemon_amd as sd
+    import headline_inputs as hi
+
+    S, F = rxf.shape[0], rxf.shape[1]
+
+    def digests():
+        tx = sd.TxPipe(ctx, S, hi.TX_LOG2_INTERP)
+        iq = tx.process(rxf)
+        ctx.synchronize()
+        return [hashlib.sha256(iq[s].contiguous().cpu().numpy().tobytes()).hexdigest() for s in range(S)]
+
+    c0 = ctx.counter("dec_rows_exceeded")
+    got = digests()
+    exceeded = ctx.counter("dec_rows_exceeded") - c0
+    gold = None
+    if kind == "hash":
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "headline_golden.json")) as f:
+                T = json.load(f)["tx_bank8"]
+            if (1 << T["log2n"]) == n and S == len(T["seeds"]) and F == T["frames"] and T["keep_seed"] == hi.TX_KEEP_SEED:
+                gold = T["iq_sha256"]
+        except Exception:
+            gold = None
+    what = "sha256 of every stream's whole interpolated output of one step"
+    if gold is not None:
+        return {"ok": got == gold and exceeded == 0, "streams": S, "what": what, "dec_rows_exceeded": exceeded,
+                "against": "tests/golden/headline_golden.json tx_bank8 (oracle cm256_decode + compiled reference interpolate16_cen)"}
+    ctx.set_option("dec_path", "dense")
+    try:
+        exp = digests()
+    finally:
+        ctx.set_option("dec_path", "syndrome")
+    return {"ok": got == exp and exceeded == 0, "streams": S, "what": what, "dec_rows_exceeded": exceeded,
+            "against": "the dense decoder path of this library on the same input (no committed digest for this geometry)"}
 
 
 def verify_step(ctx, x, ids, kind):
@@ -319,16 +369,39 @@ def verify_step(ctx, x, ids, kind):
             "streams": S, "kernel_path": path, "what": "sha256 of every stream's whole frame stream of one step"}
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-execute the same command line under
+    torch.distributed.run, one rank per GPU on this node, rendezvous on 127.0.0.1 (the container's host name may not resolve).
+    nccl (= RCCL over xGMI) needs N visible GPUs; --backend gloo is the explicit dry run of the N > 1 path on a smaller box."""
+    import socket
+    import subprocess
+
+    if args.backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        print("bench: --gpus %d but %d GPU(s) visible; pass --backend gloo to dry-run the N > 1 path with ranks sharing GPUs"
+              % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2-samples", type=int, default=25, help="samples per stream per step (default 2^25)")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("SDRHIP_BENCH_STREAMS", "0")),
-                    help="total streams of the job, sharded s -> rank s mod G (strong scaling, e.g. 64 = BASELINE configs[4]); "
-                         "default 0 = 8 streams per GPU (weak scaling); the environment variable SDRHIP_BENCH_STREAMS sets the "
-                         "default for a driver that cannot add flags")
+    ap.add_argument("--streams", type=int, default=int(os.environ["SDRHIP_BENCH_STREAMS"]) if "SDRHIP_BENCH_STREAMS" in os.environ else None,
+                    help="total streams of the job, sharded s -> rank s mod G (strong scaling).  Default: 64 = BASELINE configs[4] "
+                         "whenever --gpus > 1 (SURVEY.md 8e: the same 64 streams at 2 / 4 / 8 GPUs), 8 streams on the one GPU at "
+                         "--gpus 1 (the headline step); 0 = 8 streams per GPU whatever N (weak scaling); the environment variable "
+                         "SDRHIP_BENCH_STREAMS sets the default for a driver that cannot add flags")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra single-GPU configurations of the `configs` key")
     ap.add_argument("--input", choices=["hash", "noise", "testsource"], default="hash",
                     help="hash: counter-based full-scale uniform noise (tests/signals.py) -- the input of the committed reference digests, "
@@ -346,6 +419,11 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to dry-run the N > 1 path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
+    if args.streams is None:
+        args.streams = 64 if args.gpus > 1 else 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain process (the way the driver starts the 1-GPU run): become the launcher of one rank per GPU
+        sys.exit(relaunch_under_torchrun(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -367,7 +445,7 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(local)
-    assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
+    assert world == args.gpus, "--gpus must equal WORLD_SIZE"
 
     import sdrdaemon_amd as sd
     from sdrdaemon_amd.engine import K_DECIMATE, K_FEC_ENCODE

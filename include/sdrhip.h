@@ -75,8 +75,14 @@ int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
  * decimal sample counts, "interp_path" = valu | mfma, "rx_fused" = 0 | 1, "dec_path" = syndrome | dense.  Every setting
  * computes the same bytes.  One knob is a promise, not a path: "dec_max_rows" = 1..128 (default 128), the most recovery
  * blocks a received frame can carry (the sender's fecblk, known from the meta block); <= 32 spares the batched decoder the
- * launches of its fallback kernel. */
+ * launches of its fallback kernel.  The promise is checked on the device: a frame that carries MORE recovery blocks than
+ * dec_max_rows is left as received (like an undecodable frame: missing originals read zero) and counted, see
+ * sdrhip_ctx_get_counter("dec_rows_exceeded"). */
 int sdrhip_ctx_set_option(sdrhip_ctx *ctx, const char *key, const char *value);
+/* Event counters of the context, kept on the device (reading one synchronises the context's stream).  Keys:
+ * "dec_rows_exceeded" = frames, since the context was created, that the batched decoder (sdrhip_fec_decode_frames,
+ * sdrhip_tx_process) left unrepaired because they carried more recovery blocks than the dec_max_rows option allows. */
+int sdrhip_ctx_get_counter(sdrhip_ctx *ctx, const char *key, uint64_t *value);
 /* Average duration in milliseconds of the kernels launched between timing_begin and
  * timing_end on the context's stream, measured with hipEvents on that stream (what
  * bench.py's roofline object reports). */
@@ -101,7 +107,8 @@ int sdrhip_decimators_create(sdrhip_ctx *ctx, int nstreams, int hb_variant, sdrh
 void sdrhip_decimators_destroy(sdrhip_decimators *d);
 int sdrhip_decimators_reset(sdrhip_decimators *d); /* back to the constructor's zero state */
 /* What the bank's last cascade launch was (diagnostics: bench.py labels its roofline kernel with it, the parity tests
- * assert that they ran the benchmarked geometry).  path: 0 = no cascade launch yet, 1 = VALU kernel (nseg segments per
+ * assert that they ran the benchmarked geometry).  path: 0 = the last call launched no cascade kernel (none yet, an empty call,
+ * decimate1 and the filter-less decimate2 / 4_inf / _sup), 1 = VALU kernel (nseg segments per
  * stream), 2 = matrix-core kernel (per stream: VALU head [0, head), wps waves x 8 spans of `span` samples, VALU tail from
  * tail_start in npieces - 1 pieces). */
 typedef struct sdrhip_decim_plan {

@@ -23,7 +23,7 @@ HB_EO1, HB_DB = 0, 1
 UDPSIZE, NB_ORIGINAL, BLOCK_BYTES, SAMPLES_PER_BLOCK, SAMPLES_PER_FRAME = 512, 128, 508, 127, 16129
 
 EXPORTS = [
-    "sdrhip_last_error", "sdrhip_device_count", "sdrhip_ctx_create", "sdrhip_ctx_destroy", "sdrhip_ctx_synchronize", "sdrhip_ctx_set_option", "sdrhip_decimators_last_plan", "sdrhip_rx_last_plan", "sdrhip_rx_set_pipelined", "sdrhip_rx_flush",
+    "sdrhip_last_error", "sdrhip_device_count", "sdrhip_ctx_create", "sdrhip_ctx_destroy", "sdrhip_ctx_synchronize", "sdrhip_ctx_set_option", "sdrhip_ctx_get_counter", "sdrhip_decimators_last_plan", "sdrhip_rx_last_plan", "sdrhip_rx_set_pipelined", "sdrhip_rx_flush",
     "sdrhip_ctx_timing_begin", "sdrhip_ctx_timing_end", "sdrhip_ctx_kernel_timing", "sdrhip_ctx_kernel_timing_read", "sdrhip_decimators_create", "sdrhip_decimators_destroy",
     "sdrhip_decimators_reset", "sdrhip_decimate", "sdrhip_interpolators_create", "sdrhip_interpolators_destroy",
     "sdrhip_interpolators_reset", "sdrhip_interpolate", "sdrhip_cm256_encode", "sdrhip_cm256_decode",
@@ -70,6 +70,7 @@ def load():
     lib.sdrhip_ctx_destroy.restype = None
     lib.sdrhip_ctx_synchronize.argtypes = [vp]
     lib.sdrhip_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.sdrhip_ctx_get_counter.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
     lib.sdrhip_decimators_last_plan.argtypes = [vp, C.POINTER(DecimPlan)]
     lib.sdrhip_rx_last_plan.argtypes = [vp, C.POINTER(DecimPlan)]
     lib.sdrhip_ctx_timing_begin.argtypes = [vp]

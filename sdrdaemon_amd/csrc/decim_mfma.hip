@@ -101,19 +101,9 @@ template <int N, class F> __device__ __forceinline__ void mf_static_for(F &&f)
     mf_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-#ifndef MF_ABL
-#define MF_ABL 0 // timing experiments (wrong results): 1 no MFMAs, 2 no recombination, 8 no limb packs, 16 no packs of the raw samples
-#endif
 __device__ __forceinline__ int4_t mfma(int4_t a, int4_t b, int4_t c)
 {
-#if MF_ABL & 1
-    asm volatile("" : "+v"(c) : "v"(a), "v"(b));
-    return c;
-#elif MF_ABL & 32 // every MFMA twice
-    return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0), 0, 0, 0);
-#else
     return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
-#endif
 }
 __device__ __forceinline__ unsigned perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 
@@ -139,8 +129,6 @@ struct MfOut {
     unsigned *dump;       // 16 bytes per lane that swallow the stores of the warm-up period (no branch in the loop body)
     int store;            // 0 during warm-up
     int norm, trunk;
-    unsigned *wc;         // (MF_ABL 4096 experiment)
-    unsigned hold[4];     // the packed outputs of the even tile of a pair (stores go out as full 128-byte lines, see mf_stage)
 };
 
 __device__ __forceinline__ int sbfe16(unsigned v, int off) { return (int)__builtin_amdgcn_sbfe((int)v, (unsigned)off, 16u); }
@@ -178,14 +166,8 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
         int4_t g1 = mfma(Ah0, st.O[0][1], z);
         int4_t g2 = mfma(Ah1, st.O[0][1], z);
         g1 = mfma(Ah1, st.O[0][0], g1);
-#if MF_ABL & 2
-        asm volatile("" ::"v"(g1), "v"(g2));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = (unsigned)g0[r];
-#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = lshl_add(opaque(lshl_add((unsigned)g2[r], 8, (unsigned)g1[r])), 8, (unsigned)g0[r]);
-#endif
     } else {
         const int4_t cN = {k.cinN, k.cinN, k.cinN, k.cinN};
         int4_t g0 = mfma(Ah0, st.O[S][0], cN);
@@ -194,32 +176,17 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
         int4_t g3 = mfma(Ah1, st.O[S][2], z);
         g1 = mfma(Ah1, st.O[S][0], g1);
         g2 = mfma(Ah1, st.O[S][1], g2);
-#if MF_ABL & 2
-        asm volatile("" ::"v"(g1), "v"(g2), "v"(g3));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = (unsigned)g0[r];
-#else
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             acc[r] = lshl_add(opaque(lshl_add(opaque(lshl_add((unsigned)g3[r], 8, (unsigned)g2[r])), 8, (unsigned)g1[r])), 8, (unsigned)g0[r]);
-#endif
     }
 
-#if MF_ABL & 64 // two more shift-adds per output
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = lshl_add(opaque(lshl_add(opaque(acc[r]), 1, acc[r])), 2, acc[r]);
-#endif
     if constexpr (S < NS - 1) {
         // outputs 4q .. 4q+3 of this tile as 19-bit fields u = acc >>> 13 (limbs: bytes 0, 1 and bits 16-18).  r = 1, 3
         // are odd inputs of stage S+1 (entries 8 I + 2q, + 1 of its odd plane), r = 0, 2 the same entries of its even plane
         constexpr int SIG = I & 1, J = I >> 1;
         const unsigned X = 0x80808080u, X2 = 0x04040404u;
         const unsigned u0 = acc[0] >> 13, u1 = acc[1] >> 13, u2 = acc[2] >> 13, u3 = acc[3] >> 13;
-#if MF_ABL & 8
-        asm volatile("" : "+v"(st.O[S + 1][0]), "+v"(st.O[S + 1][1]), "+v"(st.O[S + 1][2]) : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
-        if constexpr (SIG == 1) mf_stage<NS, S + 1, J>(st, k, oc, comp);
-        return;
-#endif
         const unsigned po = perm(u3, u1, 0x05010400u), po2 = perm(u3, u1, 0x0c0c0602u);
         const unsigned pe = perm(u2, u0, 0x05010400u), pe2 = perm(u2, u0, 0x0c0c0602u);
         if constexpr (SIG == 0) {
@@ -260,46 +227,13 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
             const int other = __builtin_amdgcn_update_dpp(0, o, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
             pk[r] = final_pack(comp ? other : o, comp ? o : other, oc.norm, oc.trunk);
         }
-#ifndef MF_PAIR
-#define MF_PAIR 0 // measured: no difference (0.2359 against 0.2352 ms); the cost of the stores is not their granularity
-#endif
-        // Lanes n = 2p (I) and 2p + 1 (Q) hold the same four packed samples.  Stored as they come, a tile is 64 bytes per span,
-        // written twice.  On the memory skeleton of this kernel those 67 MB of scattered writes cost as much as 250 MB of reads
-        // (0.224 ms against 0.171 ms with the stores aimed at one cached line), although the same stores ALONE take 0.01 ms
-        // (tools/dma_probe.hip): it is the mix of the write stream with 5 TB/s of reads.  Experiment kept behind MF_PAIR: two tiles
-        // make one store (the I lane writes the even tile's samples, the Q lane the odd tile's: one full 128-byte line per span and
-        // instruction, nothing written twice) -- same launch time, so granularity is not what the writes cost; off by default.
-        constexpr int NF = mf_period<NS>() >> (NS - 1 - mf_nfixed(NS)) >> mf_nfixed(NS); // final tiles per period
-        if constexpr (MF_PAIR && NF % 2 == 0) {
-            if constexpr ((I & 1) == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) oc.hold[r] = pk[r];
-                return;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pk[r] = comp ? pk[r] : oc.hold[r];
-            }
-        }
-        constexpr bool PAIRED = MF_PAIR && NF % 2 == 0;
-        unsigned *dst = oc.store ? oc.p + (PAIRED && comp ? 16 : 0) : oc.dump;
-#if MF_ABL & 2048 // (timing experiment: every store goes to the dump slot)
-        dst = oc.dump;
-#endif
-#if MF_ABL & 4096 // (timing experiment, wrong layout: a wave's stores are contiguous, 1 KiB per instruction)
-        dst = oc.store ? oc.wc : oc.dump;
-        oc.wc += oc.store ? 128 : 0;
-#endif
-#if MF_ABL & 128 // no global stores
-        asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(dst));
-#elif defined(MF_STV) // store experiments: 1 = only the I lane of a pair stores, 2 = non-temporal, 3 = both
-        if (!(MF_STV & 1) || !comp) {
-            if (MF_STV & 2) __builtin_nontemporal_store((uint4_t){pk[0], pk[1], pk[2], pk[3]}, reinterpret_cast<uint4_t *>(dst));
-            else *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
-        }
-#else
+        // (Stored as they come a tile is 64 bytes per span, written twice.  On the memory skeleton of this kernel those 67 MB of
+        // scattered writes cost as much as 250 MB of reads although the same stores ALONE take 0.01 ms (tools/dma_probe.hip): it
+        // is the mix of the write stream with 5 TB/s of reads, not the granularity -- pairing two tiles into one 128-byte store
+        // changed nothing: tools/experiments_r03/decim_mfma_experiments.patch, MF_PAIR.)
+        unsigned *dst = oc.store ? oc.p : oc.dump;
         *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
-#endif
-        oc.p += oc.store ? (PAIRED ? 32 : 16) : 0;
+        oc.p += oc.store ? 16 : 0;
     }
 }
 
@@ -328,10 +262,6 @@ template <int NS, int I> __device__ __forceinline__ void mf_front(MfState<NS> &s
 // The same front end fed from LDS: both lanes of an I / Q pair read BOTH 16-byte pieces of their column's step (first half rA,
 // second half rB; the same addresses: an LDS broadcast) and pick their own component -- no exchange with the neighbour (2 DPP moves
 // and 2 v_perm less per step: VALU issue is what bounds the kernel; the second ds_read_b128 issues on the LDS port).
-#ifndef MF_FRONT2
-#define MF_FRONT2 0 // measured (tools/experiments_r03/exp25.sh, 4 interleaved rounds): 0.2359-0.2381 ms with it, 0.2356-0.2412 without: 4 VALU fewer per step
-                    // change nothing -- with the DMA ring the kernel sits on its memory skeleton (0.225 ms with its stores), not on VALU issue
-#endif
 template <int NS, int I> __device__ __forceinline__ void mf_front2(MfState<NS> &st, const MfConst &k, MfFront &f, const uint4_t rA, const uint4_t rB)
 {
     constexpr int i = I;
@@ -358,134 +288,23 @@ template <int NS, int I> __device__ __forceinline__ void mf_front2(MfState<NS> &
 //  * a lane reads its 16 bytes of a step back with one ds_read_b128 (issued one step ahead).  The 1-KiB block of span p
 //    starts 72 p + 2 (p >> 2) sixteen-byte units into the group: the sixteen lanes of every ds_read_b128 service group
 //    (MI355X_MICROARCH.md, LDS table) then hit sixteen distinct 4-bank columns.
-#ifndef MF_DMA
-#define MF_DMA 1
-#endif
 constexpr int MF_GROUP_BYTES = 9216;             // 8 blocks of 1 KiB + their skew
 constexpr int MF_WAVE_RING = 4 * MF_GROUP_BYTES; // bytes of LDS per wave
 // decimate16 only: measured with 3 interleaved rounds (tools/experiments_r03/exp24.sh), register ring against LDS-DMA ring: decimate16 0.2445 / 0.2363 ms,
 // decimate32 0.2512 / 0.2537, decimate64 0.2693 / 0.2947 (their warm-up and the ring's run-ahead past the span grow with the ratio)
-__host__ __device__ constexpr bool mf_dma_applies(int ns) { return MF_DMA && ns == 4; } // (period of 32 steps; one workgroup per CU)
+__host__ __device__ constexpr bool mf_dma_applies(int ns) { return ns == 4; } // (period of 32 steps; one workgroup per CU)
 __host__ __device__ constexpr int mf_block_units(int p) { return 72 * p + 2 * (p >> 2); }
 
 template <int SLOT, int D> __device__ __forceinline__ void mf_dma_issue(unsigned ring, unsigned voff, unsigned long long span_base)
 {
     constexpr int off = SLOT * MF_GROUP_BYTES + 16 * mf_block_units(D);
     // M0 = LDS byte address of the block (wave-uniform); the lanes' 16 bytes land at M0 + 16 * lane
-#ifndef MF_NT
-#define MF_NT 1
-#endif
-#if MF_NT // streamed once: non-temporal (tools/dma_probe.hip: 7.1 TB/s against 6.2 TB/s with the default policy)
     asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3 nt" ::"v"(voff), "s"(ring), "n"(off), "s"(span_base) : "memory", "scc");
-#else
-    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3" ::"v"(voff), "s"(ring), "n"(off), "s"(span_base) : "memory", "scc");
-#endif
 }
 
-// ---- loader wave (round 3, second step).  With the DMAs in the compute waves' own instruction stream a step still pays ~50
-// cycles of issue per DMA and ~10 % of s_waitcnt (arithmetic alone: 0.19 ms; with its DMAs: 0.24 ms).  So a FIFTH wave per
-// workgroup does nothing but feed the four rings, and the compute waves contain no load at all: every 8 steps (one group) all
-// five waves meet at one s_barrier -- in front of barrier k + 1 the loader has issued the 32 DMAs of group k + 3 (four waves x
-// eight spans, into the slot the compute waves left at barrier k) and has waited (vmcnt) until group k + 1 has landed; behind
-// it the compute waves start group k + 1.  The four compute waves run the same instruction stream on their own SIMDs, the
-// loader shares SIMD 0 with one of them and issues on other ports (scalar / vector memory).
-#ifndef MF_LOADER
-#define MF_LOADER 0 // measured (tools/experiments_r03/exp16.sh, 5 interleaved rounds): 0.244-0.252 ms against 0.232-0.238 ms with the DMAs in the compute waves
-#endif
-constexpr int MF_NT5 = 256 + 64 * (MF_LOADER > 0 ? MF_LOADER : 1); // threads of a matrix-core workgroup with its loader wave(s)
-
-__device__ __forceinline__ void mf_dma_issue_rt(unsigned m0v, unsigned voff, unsigned long long span_base)
-{
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" ::"v"(voff), "s"(m0v), "s"(span_base) : "memory");
-}
-
-// ngroups = groups of 8 steps every compute wave of the launch walks (4 per period)
-// MF_LOADER = number of loader waves per workgroup (1, 2 or 4): loader j feeds the compute waves j * 4 / MF_LOADER .. of its
-// workgroup (NW of them).  One loader holds at most 64 requests in flight (6-bit vmcnt): ~25-30 GB/s per CU, the whole kernel's need.
-__device__ __forceinline__ void mf_loader(const DecimArgs &a, int bx, unsigned lds_addr, size_t W, int ngroups, int w0, int NW)
-{
-    const int lane = threadIdx.x & 63;
-    const int total = a.nstreams * a.mf_wps;
-    const size_t S = a.mf_span;
-    unsigned long long base[4];
-    int live = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const int gw = bx * 4 + w0 + w;
-        if (w < NW && gw < total) {
-            const int stream = gw / a.mf_wps, ws = gw - stream * a.mf_wps;
-            base[w] = (unsigned long long)(reinterpret_cast<const char *>(a.in) + ((size_t)stream * a.in_stride + a.mf_head + (size_t)ws * 8 * S - W) * 4);
-            live = w + 1;
-        } else {
-            base[w] = 0;
-        }
-    }
-    const unsigned ring0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr + (unsigned)w0 * MF_WAVE_RING));
-    const unsigned long long sstep = (unsigned long long)S * 4;
-    auto issue_group = [&](int g) { // the 8 DMAs of group g of every live compute wave of this loader
-        const unsigned voff = 16u * (unsigned)lane + 1024u * (unsigned)g;
-        const unsigned slot = ring0 + (unsigned)(g & 3) * MF_GROUP_BYTES;
-        for (int w = 0; w < live; ++w) {
-            unsigned long long sb = base[w];
-            unsigned m = slot + (unsigned)w * MF_WAVE_RING;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                mf_dma_issue_rt(m + 16u * (unsigned)mf_block_units(d), voff, sb);
-                sb += sstep;
-            }
-        }
-    };
-    // "group g has landed": 2 x 8 x NW DMAs (groups g + 1, g + 2) may still be in flight behind its last one (the counter
-    // holds 63 at most: with four waves per loader one more DMA is awaited)
-    auto wait_two_groups = [&]() {
-        if (live < NW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (a partly filled workgroup: fewer DMAs per group)
-        else if (NW == 4) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-        else if (NW == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    };
-    issue_group(0); issue_group(1); issue_group(2);
-    wait_two_groups(); // barrier 0: group 0 has landed
-    __builtin_amdgcn_s_barrier();
-    for (int r = 0; r + 1 < ngroups; ++r) {
-        if (r + 3 < ngroups) issue_group(r + 3);
-        // group r + 1 must have landed before barrier r + 1
-        if (r + 3 < ngroups) wait_two_groups();
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// compute side of the loader-wave variant: no loads, one barrier per group
-template <int NS>
-__device__ __forceinline__ void mf_loop_fed(MfState<NS> &st, const MfConst &k, MfOut &oc, MfFront &fr, unsigned lds_addr, int nper, int WP, int p, int comp, int q)
-{
-    constexpr int P = mf_period<NS>();
-    static_assert(P == 32, "the ring turns once per period");
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned ring = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr + (unsigned)wv * MF_WAVE_RING));
-    const __attribute__((address_space(3))) char *lrd =
-        (const __attribute__((address_space(3))) char *)(size_t)(ring + 16u * (unsigned)(72 * p + 2 * (p >> 2) + 4 * comp + q));
-    __builtin_amdgcn_s_barrier(); // barrier 0: group 0 has landed
-    uint4_t r = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd);
-    for (int per = 0; per < nper; ++per) {
-        oc.store = per >= WP;
-        mf_static_for<P>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            constexpr int i1 = (i + 1) % P;
-            if constexpr (i1 % 8 == 0) {
-                // the last step of a group: its data is in `r`; behind the barrier the next group has landed and the loader may
-                // overwrite this one.  (The very last barrier of the launch has no partner: skipped.)
-                if (i1 != 0 || per + 1 < nper) __builtin_amdgcn_s_barrier();
-            }
-            const uint4_t rn = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd + (i1 / 8) * MF_GROUP_BYTES + 128 * (i1 % 8));
-            mf_front<NS, i>(st, k, fr, r);
-            mf_stage<NS, 0, i>(st, k, oc, comp);
-            r = rn;
-        });
-    }
-}
-
+// (A loader-wave variant -- a fifth wave per workgroup issues all DMAs, the compute waves meet it at one s_barrier per group -- was
+// measured slower, 0.244-0.252 ms against 0.232-0.238 ms with the DMAs in the compute waves: tools/experiments_r03/
+// decim_mfma_experiments.patch, MF_LOADER.)
 template <int NS>
 __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st, const MfConst &k, MfOut &oc, MfFront &fr, unsigned lds_addr,
                                             const char *wbase, size_t S, int nper, int WP, int lane, int p, int comp, int q)
@@ -502,7 +321,7 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
     }
     // what this lane reads back: bytes 128 j + 64 comp + 16 q of step j of span p
     const __attribute__((address_space(3))) char *lrd =
-        (const __attribute__((address_space(3))) char *)(size_t)(ring + 16u * (unsigned)(mf_block_units(0) + 72 * p + 2 * (p >> 2) + (MF_FRONT2 ? 0 : 4 * comp) + q));
+        (const __attribute__((address_space(3))) char *)(size_t)(ring + 16u * (unsigned)(mf_block_units(0) + 72 * p + 2 * (p >> 2) + 4 * comp + q));
     unsigned voff[4];
     const unsigned vmax = 16u * (unsigned)lane + 1024u * (unsigned)(4 * nper - 1); // offset of the wave's last group
 #pragma unroll
@@ -517,47 +336,21 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
     }
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // group 0 has landed
     uint4_t r = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd);
-#if MF_FRONT2
-    uint4_t r2 = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd + 64);
-#endif
     for (int per = 0; per < nper; ++per) {
         oc.store = per >= WP;
         mf_static_for<P>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             constexpr int i1 = (i + 1) % P;
             if constexpr (i1 % 8 == 0) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); // the next group has landed
-#if MF_FRONT2
-            const uint4_t rn2 = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd + (i1 / 8) * MF_GROUP_BYTES + 128 * (i1 % 8) + 64);
-#endif
-#if MF_ABL & 1024 // (timing experiment: no read-back from the ring)
-            uint4_t rn = r;
-            asm volatile("" : "+v"(rn));
-#else
             const uint4_t rn = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd + (i1 / 8) * MF_GROUP_BYTES + 128 * (i1 % 8));
-#endif
             constexpr int g = (i / 8 + 3) % 4;
-#if !(MF_ABL & 512) // (timing experiment: no DMAs in the loop)
             mf_dma_issue<g, i % 8>(ring, voff[g], sb[i % 8]);
-#endif
             // (next period's group of this slot; past the wave's last group the DMAs re-read that last group -- cache hits, no
             // HBM traffic, and the vmcnt arithmetic stays as it is)
-#ifdef MF_NOCLAMP // (A / B)
-            if constexpr (i % 8 == 7) voff[g] += 4096u;
-#else
             if constexpr (i % 8 == 7) voff[g] = min(voff[g] + 4096u, vmax);
-#endif
-#if MF_ABL & 16
-            asm volatile("" : "+v"(st.O[0][0]), "+v"(st.O[0][1]) : "v"(r));
-#elif MF_FRONT2
-            mf_front2<NS, i>(st, k, fr, r, r2);
-#else
             mf_front<NS, i>(st, k, fr, r);
-#endif
             mf_stage<NS, 0, i>(st, k, oc, comp);
             r = rn;
-#if MF_FRONT2
-            r2 = rn2;
-#endif
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no DMA may outlive the workgroup's LDS allocation
@@ -612,7 +405,6 @@ template <int NS, bool DMA = true> __device__ __forceinline__ void mf_wave(const
         unsigned *obase = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
         const size_t first = ((wave_start + (size_t)p * S) >> L) + 4u * (unsigned)q; // this lane's first output
         oc.p = obase + first;
-        oc.wc = obase + (wave_start >> L) + 4u * (unsigned)(p + 8 * q);
     }
 
     MfState<NS> st;
@@ -631,30 +423,16 @@ template <int NS, bool DMA = true> __device__ __forceinline__ void mf_wave(const
     // {own half, received half} -> {first, second} half of the block: the I lane loaded the first half
     fr.sel_lo = comp ? 0x05040100u : 0x01000504u; fr.sel_hi = comp ? 0x07060302u : 0x03020706u;
     fr.ev_lo = 0u; fr.ev_hi = 0u;
-#if MF_DMA
     if constexpr (DMA && mf_dma_applies(NS)) {
-#if MF_LOADER
-        mf_loop_fed<NS>(st, k, oc, fr, lds_addr, nper, WP, p, comp, q);
-#else
         mf_loop_dma<NS>(a, st, k, oc, fr, lds_addr, wbase, S, nper, WP, lane, p, comp, q);
-#endif
         return;
     }
-#endif
     uint4_t ld[D];
     // step g of this lane's column pair: 128 bytes at src + 128 g.  No bounds handling: the loads run D steps past the
     // end of the span, i.e. into the next span or (last span of a stream) the first 32 D samples of the tail that
     // plan_decimate_mfma() guarantees
     const char *src = wbase + loff;
-#if MF_ABL & 256 // timing experiment (wrong data): wave-contiguous loads, 1 KiB per instruction, same bytes per wave in total
-    src = wbase + 16 * lane; // the wave walks its 8 spans' worth of bytes as one contiguous region, 1 KiB per step
-#define MF_LDSTRIDE 1024
-#else
 #define MF_LDSTRIDE 128
-#endif
-#ifdef MF_SKEW // experiment: de-phase the waves' addresses (wrong data)
-    src += (size_t)(gw % MF_SKEW) * (4096 / MF_SKEW);
-#endif
     // (Tried: loads and s_waitcnt vmcnt(D - 1) issued by hand in asm, because hipcc, which counts outstanding VMEM
     // operations exactly only inside a basic block, drains the ring with a vmcnt(0) at the top of every period: same
     // launch time, 0.255 ms both ways, and the register allocator may copy an asm load's destination before the wait.)
@@ -667,16 +445,7 @@ template <int NS, bool DMA = true> __device__ __forceinline__ void mf_wave(const
             constexpr int i = decltype(ic)::value;
             constexpr int slot = i % D;
             const uint4_t r = ld[slot];
-#if MF_ABL & 512 // timing experiment (wrong data): no loads in the loop, the arithmetic runs on stale registers
-            asm volatile("" : "+v"(ld[slot]));
-#else
             ld[slot] = SDRHIP_STREAM_LOAD(reinterpret_cast<const uint4_t *>(src + MF_LDSTRIDE * (i + D)));
-#endif
-#if MF_ABL & 16
-            asm volatile("" : "+v"(st.O[0][0]), "+v"(st.O[0][1]) : "v"(r));
-            mf_stage<NS, 0, i>(st, k, oc, comp);
-            return;
-#endif
             mf_front<NS, i>(st, k, fr, r);
             mf_stage<NS, 0, i>(st, k, oc, comp);
         });
@@ -686,8 +455,7 @@ template <int NS, bool DMA = true> __device__ __forceinline__ void mf_wave(const
 
 // grid.x = the matrix-core workgroups (four waves = four groups of 8 spans each), then nstreams * mf_npieces VALU
 // workgroups (head + tail pieces of every stream)
-__host__ __device__ constexpr bool mf_loader_applies(int ns) { return MF_LOADER && mf_dma_applies(ns); }
-__host__ __device__ constexpr int mf_block_threads(int ns) { return mf_loader_applies(ns) ? MF_NT5 : NT; }
+__host__ __device__ constexpr int mf_block_threads(int) { return NT; }
 
 template <int L, bool PACK16> __global__ __launch_bounds__(mf_block_threads(L), mf_dma_applies(L) ? 1 : MF_WAVES) void decim_mfma_kernel(DecimArgs a)
 {
@@ -699,18 +467,6 @@ template <int L, bool PACK16> __global__ __launch_bounds__(mf_block_threads(L), 
     // that got two of them while the short VALU pieces held slots elsewhere doubled the time of the whole launch.
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
     const int bx = blockIdx.x;
-    if constexpr (mf_loader_applies(L)) {
-        if (threadIdx.x >= NT) { // a loader wave of a matrix-core workgroup; nothing to do in a VALU piece
-            if (bx < nmf) {
-                constexpr size_t W = (size_t)64 << L;
-                constexpr int NW = 4 / (MF_LOADER > 0 ? MF_LOADER : 1);
-                const int nper = (int)((W + a.mf_span) / 32) / mf_period<L>();
-                const int j = __builtin_amdgcn_readfirstlane((int)((threadIdx.x - NT) >> 6));
-                mf_loader(a, bx, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds, W, 4 * nper, j * NW, NW);
-            }
-            return;
-        }
-    }
     if (bx >= nmf) {
         const int lx = bx - nmf;
         const int stream = lx / a.mf_npieces, piece = lx - stream * a.mf_npieces;

@@ -227,6 +227,8 @@ struct DecPlanArgs {
     uint8_t *block0_out;       // may be NULL
     int nframes;
     uint8_t *plan2;            // [nframes][DEC128_PLAN_BYTES] records for gf_decode128_kernel (NULL: dense path only)
+    int max_rows;              // the caller's promise (ctx option dec_max_rows): no frame carries more recovery blocks
+    unsigned *stats;           // [0] += frames that broke the promise (they stay as received; sdrhip_ctx_get_counter)
 };
 
 // Per-frame record of the syndrome decoder (gf_decode128_kernel): where every original lies in the received array, which
@@ -289,6 +291,12 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
 
     const int N = nrec;
     bool ok = N > 0 && !dup;
+    if (N > a.max_rows) {
+        // more recovery blocks than the caller promised (dec_max_rows sized the launches behind this one): the frame is left
+        // as received -- like an undecodable one -- and COUNTED, never half repaired
+        ok = false;
+        if (p == 0) atomicAdd(a.stats, 1u);
+    }
     Dec128Plan *pl = a.plan2 ? reinterpret_cast<Dec128Plan *>(a.plan2 + (size_t)f * DEC128_PLAN_BYTES) : nullptr;
     const bool syn = pl && N <= DEC128_MAXN; // this frame's repair (if any) is the syndrome kernel's
     if (pl) {
@@ -682,10 +690,13 @@ namespace sdrhip {
 
 hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices_dev,
                                          const uint8_t *explog, const uint8_t *tab, int nframes, uint8_t *payload_out,
-                                         size_t payload_frame_bytes, uint8_t *block0_out, int max_rows, hipStream_t stream)
+                                         size_t payload_frame_bytes, uint8_t *block0_out, int max_rows, unsigned *stats, hipStream_t stream)
 {
     if (nframes <= 0) return hipSuccess;
+    if (max_rows < 1) max_rows = 1;
+    if (max_rows > 128) max_rows = 128;
     DecPlanArgs p;
+    p.max_rows = max_rows; p.stats = stats;
     p.rx = rx; p.rx_frame_bytes = rx_frame_bytes; p.indices = indices_dev; p.explog = explog;
     p.coef = d.coef; p.pmap = d.pmap; p.zmap = d.zmap; p.pdst = d.pdst; p.zdst = d.zdst; p.nrec = d.nrec;
     p.payload_out = payload_out; p.payload_frame_bytes = payload_frame_bytes; p.block0_out = block0_out; p.nframes = nframes;
@@ -716,8 +727,6 @@ hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *
     DecApplyArgs a;
     a.in = rx; a.in_frame_bytes = rx_frame_bytes; a.out = payload_out; a.out_frame_bytes = payload_frame_bytes; a.out_pitch = 508;
     a.coef = d.coef; a.dst = d.pdst; a.nrec = d.nrec; a.tab = tab; a.which = 0; a.nframes = nframes;
-    if (max_rows < 1) max_rows = 1;
-    if (max_rows > 128) max_rows = 128;
     const int groups = (nframes + 1) / 2;
     if (max_rows <= 16) hipLaunchKernelGGL(gf_decode_apply_kernel<4>, dim3(groups, 1), dim3(GF_NT), 0, stream, a);
     else hipLaunchKernelGGL(gf_decode_apply_kernel<6>, dim3(groups, (max_rows + 23) / 24), dim3(GF_NT), 0, stream, a);

@@ -21,6 +21,7 @@
 //  * segment 0 takes the histories from the bank state, other segments rebuild them from the
 //    64 preceding inputs (the cascade's memory is 43 inputs) with stores suppressed.
 #include "interp_body.h"
+#include "interp_wave.h"
 
 namespace sdrhip {
 namespace {
@@ -30,6 +31,19 @@ template <int L> __global__ __launch_bounds__(NT) void interp_kernel(InterpArgs 
 {
     __shared__ __attribute__((aligned(16))) int lds[IGeo<(L == 6) ? 5 : L>::ldsDw];
     interp_segment<L>(a, blockIdx.x, blockIdx.y, lds);
+}
+
+// K5w: one wave per workgroup, one time slice of one stream per wave, no barrier (interp_wave.h)
+template <int L> __global__ __launch_bounds__(WNT) void interp_wave_kernel(InterpArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int lds[WGeo<(L == 6) ? 5 : L>::ldsDw];
+    interp_wave_segment<L>(a, blockIdx.x, blockIdx.y, lds);
+}
+
+template <int L> hipError_t launch_w(const InterpArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL((interp_wave_kernel<L>), dim3(a.nseg, a.nstreams), dim3(WNT), 0, stream, a);
+    return hipGetLastError();
 }
 
 template <int L> hipError_t launch_l(const InterpArgs &a, hipStream_t stream)
@@ -49,6 +63,43 @@ void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_s
     while (per > 1 && ((nsub + per - 1) / per) * (size_t)nstreams < 2048) per >>= 1;
     *nsub_per_seg = (int)per;
     *nseg = (int)((nsub + per - 1) / per);
+}
+
+// K5w: blocks of 128 inputs; the segments are sized so that the launch is a whole number of rounds of the chip's wave slots
+// (waves_per_cu resident one-wave workgroups per CU), at least 8 blocks each (the warm-up of a segment is half a block)
+void plan_interpolate_wave(int log2interp, size_t n_in, int nstreams, int n_cu, size_t seg_override, int *nsub_per_seg, int *nseg)
+{
+    (void)log2interp;
+    size_t nsub = (n_in + WB - 1) / WB;
+    if (nsub == 0) nsub = 1;
+    size_t per;
+    if (seg_override) {
+        per = (seg_override + WB - 1) / WB;
+    } else {
+        const size_t slots = (size_t)n_cu * 16;
+        const size_t total = nsub * (size_t)nstreams;
+        size_t rounds = (total / 16 + slots - 1) / slots; // rounds of segments of ~16 blocks
+        if (rounds == 0) rounds = 1;
+        const size_t per_stream = (rounds * slots + nstreams - 1) / nstreams; // segments per stream
+        per = (nsub + per_stream - 1) / per_stream;
+        if (per < 8) per = 8;
+    }
+    if (per > nsub) per = nsub;
+    if (per < 1) per = 1;
+    *nsub_per_seg = (int)per;
+    *nseg = (int)((nsub + per - 1) / per);
+}
+
+hipError_t launch_interpolate_wave(int log2interp, const InterpArgs &a, hipStream_t stream)
+{
+    switch (log2interp) {
+    case 2: return launch_w<2>(a, stream);
+    case 3: return launch_w<3>(a, stream);
+    case 4: return launch_w<4>(a, stream);
+    case 5: return launch_w<5>(a, stream);
+    case 6: return launch_w<6>(a, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_interpolate(int log2interp, const InterpArgs &a, hipStream_t stream)

@@ -143,6 +143,8 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
         if (hipMalloc(reinterpret_cast<void **>(&c->gf_explog), sizeof(el)) != hipSuccess ||
             hipMemcpy(c->gf_explog, el, sizeof(el), hipMemcpyHostToDevice) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "upload GF(256) exp/log tables"); }
     }
+    if (hipMalloc(reinterpret_cast<void **>(&c->dec_stats), 64) != hipSuccess ||
+        hipMemset(c->dec_stats, 0, 64) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "hipMalloc decoder counters"); }
     if (hipMalloc(reinterpret_cast<void **>(&c->decim_dump), 4096) != hipSuccess) { c->decim_dump = nullptr; ctx_free(c); return fail(SDRHIP_ENOMEM, "hipMalloc decimator scratch"); }
     if (hipMalloc(reinterpret_cast<void **>(&c->fused_roles), SDRHIP_FUSED_ROLE_WORDS * 4) != hipSuccess ||
         hipMemset(c->fused_roles, 0, SDRHIP_FUSED_ROLE_WORDS * 4) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "hipMalloc role table"); }
@@ -182,7 +184,9 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
         else if (v == "mfma") c->opt.decim_path = DECIM_PATH_MFMA;
         else return fail(SDRHIP_EINVAL, "ctx_set_option: decim_path must be auto, valu or mfma");
     } else if (k == "interp_path") {
-        if (v == "valu" || v == "auto") c->opt.interp_mfma = 0;
+        if (v == "auto") { c->opt.interp_mfma = 0; c->opt.interp_wave = CtxOptions().interp_wave; }
+        else if (v == "valu") { c->opt.interp_mfma = 0; c->opt.interp_wave = 0; }
+        else if (v == "wave") { c->opt.interp_mfma = 0; c->opt.interp_wave = 1; }
         else if (v == "mfma") {
 #ifdef SDRHIP_WITH_K5M
             c->opt.interp_mfma = 1;
@@ -190,7 +194,7 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
             return fail(SDRHIP_EINVAL, "ctx_set_option: this library was built without the matrix-core interpolator experiment (make WITH_K5M=1)");
 #endif
         }
-        else return fail(SDRHIP_EINVAL, "ctx_set_option: interp_path must be valu or mfma");
+        else return fail(SDRHIP_EINVAL, "ctx_set_option: interp_path must be auto, valu, wave or mfma");
     } else if (k == "mfma_span" && isnum) c->opt.mfma_span = (size_t)num;
     else if (k == "mfma_min" && isnum) c->opt.mfma_min = (size_t)num;
     else if (k == "interp_span" && isnum) c->opt.interp_span = (size_t)num;
@@ -201,6 +205,20 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
         else return fail(SDRHIP_EINVAL, "ctx_set_option: dec_path must be syndrome or dense");
     } else if (k == "dec_max_rows" && isnum && num >= 1 && num <= 128) c->opt.dec_max_rows = (int)num;
     else return fail(SDRHIP_EINVAL, "ctx_set_option: unknown key or malformed value: %s=%s", key, value);
+    return SDRHIP_OK;
+}
+
+// Event counters kept on the device (read = one stream synchronisation + a 4-byte copy).
+extern "C" int sdrhip_ctx_get_counter(sdrhip_ctx *c, const char *key, uint64_t *value)
+{
+    if (!c || !key || !value) return fail(SDRHIP_EINVAL, "ctx_get_counter: NULL argument");
+    sdrhip::CtxLock lock_(c);
+    if (std::string(key) != "dec_rows_exceeded") return fail(SDRHIP_EINVAL, "ctx_get_counter: unknown key: %s", key);
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, c->dec_stats, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *value = v;
     return SDRHIP_OK;
 }
 
@@ -216,6 +234,7 @@ static void sdrhip::ctx_free(sdrhip_ctx *c)
     if (c->decim_dump) (void)hipFree(c->decim_dump);
     if (c->fused_roles) (void)hipFree(c->fused_roles);
     if (c->gf_explog) (void)hipFree(c->gf_explog);
+    if (c->dec_stats) (void)hipFree(c->dec_stats);
     c->dec_plan.release();
     c->pin.release();
     c->zin.release(); c->zout.release();
@@ -360,6 +379,7 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     if (L == 0) {
         // Downsampler::process m_decim == 0: copy + decimate1 (Downsampler.cpp:76-80, Decimators.cpp:22-35)
         if (n_out) *n_out = n_in;
+        d->last = DecimPlanInfo(); // (no cascade launch: last_plan reports path 0, not the previous call's plan)
         if (n_in == 0) return SDRHIP_OK;
         if (frame_mode) return fail(SDRHIP_EINVAL, "internal: frame mode needs log2decim >= 1");
         int norm = ss < 16 ? (int)(16 - ss) : 0;
@@ -373,6 +393,7 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     const size_t n_resize = n_in >> L; // out.resize(len / N)
     *sampleSize = ss + L - trunk;
     if (n_out) *n_out = n_resize;
+    d->last = DecimPlanInfo(); // (set below when a cascade kernel is launched; filter-less and empty calls report path 0)
     if (n_resize == 0) return SDRHIP_OK; // (the reference's unsigned loop bound would wrap here)
 
     if (fcpos != SDRHIP_FC_CEN && L <= 2) {
@@ -420,6 +441,12 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
                 if (e == hipSuccess) e = launch_gf_encode128(*fuse, c->stream);
             } else
             e = launch_rx_fused((int)L, pack16, a, *fuse, c->fused_roles, c->fused_tag, c->stream);
+            if (e != hipSuccess) {
+                // a fused launch that never started has not cleared the NEXT launch's unit counters (block 0 of every launch
+                // does that): start the role table over, or the next fused launch would find them exhausted and do nothing
+                (void)hipMemsetAsync(c->fused_roles, 0, SDRHIP_FUSED_ROLE_WORDS * 4, c->stream);
+                c->fused_tag = 0;
+            }
             if (fused) *fused = true;
         } else {
             e = use_mfma ? launch_decimate_mfma((int)L, pack16, a, c->stream) : launch_decimate((int)L, fcpos, pack16, a, c->stream);

@@ -108,6 +108,7 @@ struct CtxOptions {
     size_t mfma_span = 0;                  // forced span length of the matrix-core decimator (0 = planner's choice)
     size_t mfma_min = (size_t)1 << 22;     // smallest call (samples over all streams, decimate4 / 8) the matrix cores take in auto mode
     int interp_mfma = 0;
+    int interp_wave = 0;                   // interpolate4 .. 64: K5w, the barrier-free wave-private pipeline (interp_wave.h); 0 = K5
     size_t interp_span = 0;
     int rx_fused = 1;                      // pipelined Rx pipe: encoder in the decimator's launch (0 = separate launches)
     int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)
@@ -142,6 +143,7 @@ struct sdrhip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint8_t *gf_explog = nullptr;             // exp[512] + log[256] (uint16) of GF(256) for the decode planner (device)
     sdrhip::DevBuf dec_plan;                  // per-frame decode plans of the current batch (DecodeBuffers)
+    unsigned *dec_stats = nullptr;            // device counters of the batched decoder: [0] frames that broke the dec_max_rows promise
     sdrhip::PinnedBuf pin;                       // per-call upload staging (maps, frame lists)
     sdrhip::PinnedBuf zin, zout;                 // zero-copy staging of small host-pointer calls (the kernels read / write pinned host memory)
     // per-kernel-class timing with hipEvents on `stream` (sdrhip_ctx_kernel_timing)

@@ -181,6 +181,9 @@ struct InterpArgs {
 };
 hipError_t launch_interpolate(int log2interp, const InterpArgs &a, hipStream_t stream);
 void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_seg, int *nseg);
+// K5w (interp_wave.h): one-wave workgroups, blocks of 128 inputs; log2interp 2..6
+void plan_interpolate_wave(int log2interp, size_t n_in, int nstreams, int n_cu, size_t seg_override, int *nsub_per_seg, int *nseg);
+hipError_t launch_interpolate_wave(int log2interp, const InterpArgs &a, hipStream_t stream);
 bool plan_interpolate_mfma(int log2interp, size_t n_in, int nstreams, size_t span_override, InterpArgs *a);
 hipError_t launch_interpolate_mfma(int log2interp, const InterpArgs &a, hipStream_t stream);
 
@@ -268,9 +271,9 @@ struct DecodeBuffers {
     static size_t bytes(size_t nframes) { return nframes * (128 * 128 + 4 * 128 * sizeof(int16_t) + 2 * sizeof(int32_t) + DECODE_PLAN2_BYTES) + 64; }
 };
 // plan + scatter + apply, all on the stream, no host synchronisation; max_rows = upper bound of the recovery blocks a
-// frame can have used (128 when unknown)
+// frame can have used (128 when unknown); a frame that carries more is left as received and counted in stats[0]
 hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices_dev,
                                          const uint8_t *explog, const uint8_t *tab, int nframes, uint8_t *payload_out,
-                                         size_t payload_frame_bytes, uint8_t *block0_out, int max_rows, hipStream_t stream);
+                                         size_t payload_frame_bytes, uint8_t *block0_out, int max_rows, unsigned *stats, hipStream_t stream);
 
 } // namespace sdrhip

@@ -81,15 +81,17 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
 #ifdef SDRHIP_WITH_K5M
     if (c->opt.interp_mfma) use_mfma = plan_interpolate_mfma(log2interp, n_in, p->nstreams, c->opt.interp_span, &a);
 #endif
-    if (!use_mfma) plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
+    const bool use_wave = !use_mfma && c->opt.interp_wave && log2interp >= 2;
+    if (use_wave) plan_interpolate_wave(log2interp, n_in, p->nstreams, c->n_cu, c->opt.interp_span, &a.nsub_per_seg, &a.nseg);
+    else if (!use_mfma) plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
     a.mf_dump = c->decim_dump;
     hipError_t e;
     {
         KTimer kt(c, SDRHIP_K_INTERPOLATE);
 #ifdef SDRHIP_WITH_K5M
-        e = use_mfma ? launch_interpolate_mfma(log2interp, a, c->stream) : launch_interpolate(log2interp, a, c->stream);
+        e = use_mfma ? launch_interpolate_mfma(log2interp, a, c->stream) : use_wave ? launch_interpolate_wave(log2interp, a, c->stream) : launch_interpolate(log2interp, a, c->stream);
 #else
-        e = launch_interpolate(log2interp, a, c->stream);
+        e = use_wave ? launch_interpolate_wave(log2interp, a, c->stream) : launch_interpolate(log2interp, a, c->stream);
 #endif
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "interpolate launch: %s", hipGetErrorString(e));
@@ -237,12 +239,13 @@ extern "C" int sdrhip_rx_reconfigure(sdrhip_rx *rx, const sdrhip_rx_config *cfg)
                                      rx->cap_frames * old_fb, (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE, S, hipMemcpyDeviceToDevice,
                                      c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream)); // earlier launches may still use the old area
+        // (no frames wait for delivery here: a fecblk change with late.have set was refused above)
         rx->old_work.release();
-        if (rx->late.have) { rx->old_work = rx->work; rx->late.slot0 = SIZE_MAX; } // (still to be delivered from there)
-        else rx->work.release();
+        rx->work.release();
         rx->work = fresh;
         rx->base_slot = 0;
-        if (!rx->late.have) { rx->view_base = nullptr; rx->view_frames = 0; }
+        rx->view_base = nullptr;
+        rx->view_frames = 0;
     }
     rx->cfg = *cfg;
     return SDRHIP_OK;
@@ -263,6 +266,7 @@ extern "C" void sdrhip_rx_destroy(sdrhip_rx *rx)
 extern "C" int sdrhip_rx_frames_view(const sdrhip_rx *rx, const uint8_t **base, size_t *stream_stride_bytes, size_t *n_frames)
 {
     if (!rx || !base || !stream_stride_bytes || !n_frames) return fail(SDRHIP_EINVAL, "rx_frames_view: NULL argument");
+    sdrhip::CtxLock lock_(rx->ctx);
     *base = rx->view_base;
     *stream_stride_bytes = rx->view_stride;
     *n_frames = rx->view_frames;
@@ -278,6 +282,7 @@ extern "C" int sdrhip_rx_last_plan(const sdrhip_rx *rx, sdrhip_decim_plan *out)
 extern "C" size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in)
 {
     if (!rx) return 0;
+    sdrhip::CtxLock lock_(rx->ctx);
     const size_t now = (size_t)((rx->pending_samples + (n_in >> rx->cfg.log2decim)) / SDRHIP_SAMPLES_PER_FRAME);
     if (!rx->pipelined) return now;
     return rx->late.have && rx->late.frames > now ? rx->late.frames : now; // (a pipelined call delivers the previous call's frames)
@@ -323,7 +328,13 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     if (!rx) return fail(SDRHIP_EINVAL, "rx is NULL");
     sdrhip::CtxLock lock_(rx->ctx);
     if (n_frames) *n_frames = 0;
-    if (n_in == 0) return SDRHIP_OK;
+    if (n_in == 0) {
+        // an empty call completes nothing; in pipelined mode it still DELIVERS what the previous call completed (the header's
+        // contract: every call delivers the frames of the one before it)
+        if (rx->pipelined && rx->late.have) return sdrhip_rx_flush(rx, frames_out, frame_stride_bytes, n_frames, mem);
+        rx->view_frames = 0;
+        return SDRHIP_OK;
+    }
     if (!iq_in) return fail(SDRHIP_EINVAL, "rx_process: NULL input");
     sdrhip_ctx *c = rx->ctx;
     HIP_TRY(hipSetDevice(c->device));

@@ -59,6 +59,13 @@ class Context:
         interp_span, rx_fused; the defaults were read from the SDRHIP_* environment when the context was created"""
         check(self.lib.sdrhip_ctx_set_option(self.h, str(key).encode(), str(value).encode()))
 
+    def counter(self, key):
+        """device-side event counters (sdrhip_ctx_get_counter; synchronises): "dec_rows_exceeded" = frames the batched decoder
+        left unrepaired because they carried more recovery blocks than the dec_max_rows option promises"""
+        v = C.c_uint64(0)
+        check(self.lib.sdrhip_ctx_get_counter(self.h, str(key).encode(), C.byref(v)))
+        return v.value
+
     def timing_begin(self):
         check(self.lib.sdrhip_ctx_timing_begin(self.h))
 

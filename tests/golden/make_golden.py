@@ -87,6 +87,7 @@ def main():
     fec_golden()
     long_golden()
     headline_golden()
+    tx_headline_golden()
 
 
 def long_golden():
@@ -157,6 +158,57 @@ def headline_golden():
         json.dump(out, f, indent=0)
 
 
+def tx_headline_golden():
+    """Whole-output digests of the BENCHMARKED Tx launch: bench.py's configs[3] -- the first 128 frames of
+    every stream of the bank8 Rx run above (reference decimator -> oracle framer + encoder), 24 of 160 blocks lost per frame
+    (tests/headline_inputs.py: tx_keep_sets), the oracle's cm256_decode, then the REFERENCE's interpolate16_cen over the
+    stream of recovered frames.  -> key "tx_bank8" of headline_golden.json."""
+    import headline_inputs as hi
+    from oracle_lib import Oracle
+
+    ref, orc = Reference("eo1"), Oracle()
+    path = os.path.join(HERE, "headline_golden.json")
+    with open(path) as f:
+        out = json.load(f)
+    m = out["meta"]
+    seeds, log2n, F = out["bank8"]["seeds"], out["bank8"]["log2n"], hi.TX_FRAMES
+    keep = hi.tx_keep_sets(len(seeds) * F)
+    pay_sha, iq_sha, nrec_hist = [], [], {}
+    for s, seed in enumerate(seeds):
+        x = signals.hash_noise(1 << log2n, seed)
+        y, _ = ref.decimators().decimate(4, 2, 16, x)
+        fr = orc.framer(nb_fec_blocks=m["nb_fec"], tv_sec=m["tv_sec"], tv_usec=m["tv_usec"], center_frequency_khz=m["center_frequency_khz"],
+                        sample_rate=m["sample_rate"], sample_bytes=2, sample_bits=16)
+        frames = fr.write(y)[:F]
+        assert frames.shape[0] == F
+        payload = np.zeros((F, 127, 508), np.uint8)
+        for f in range(F):
+            allb = np.concatenate([frames[f], orc.frame_encode(frames[f], m["nb_fec"])])  # (160, 512)
+            k = keep[s * F + f]
+            data = np.ascontiguousarray(allb[k][:, 4:])
+            n_rec = int((k >= 128).sum())
+            nrec_hist[n_rec] = nrec_hist.get(n_rec, 0) + 1
+            rc, idx = orc.cm256_decode(data, k.astype(np.uint8), 128, n_rec)
+            assert rc == 0
+            got = np.zeros((128, 508), np.uint8)
+            seen = np.zeros(128, bool)
+            for i in range(128):
+                got[idx[i]] = data[i]
+                seen[idx[i]] = True
+            assert seen.all() and np.array_equal(got, frames[f][:, 4:]), "the oracle's decode must restore the frame"
+            payload[f] = got[1:]
+        iq = payload.reshape(-1).view(np.int16).reshape(-1, 2)
+        assert np.array_equal(iq, y[:F * 16129])
+        z = ref.interpolators().interpolate(hi.TX_LOG2_INTERP, iq)
+        pay_sha.append(hashlib.sha256(payload.tobytes()).hexdigest())
+        iq_sha.append(hashlib.sha256(z.tobytes()).hexdigest())
+        print("tx headline", seed, pay_sha[-1][:12], iq_sha[-1][:12], z.shape, flush=True)
+    out["tx_bank8"] = {"seeds": seeds, "log2n": log2n, "frames": F, "keep_seed": hi.TX_KEEP_SEED, "log2interp": hi.TX_LOG2_INTERP,
+                       "payload_sha256": pay_sha, "iq_sha256": iq_sha, "recovery_blocks_used_histogram": {str(k): v for k, v in sorted(nrec_hist.items())}}
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+
+
 def fec_golden():
     """FEC vectors from the REAL cm256cc library (oracle/_ref/libsdrref_cm256.so, built by `make -C oracle
     LIBCM256CCSRC=<dir>` where the library's sources exist).  Absent on this image: nothing is written and the FEC
@@ -199,6 +251,9 @@ def fec_golden():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "headline":
         headline_golden()
+        tx_headline_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tx_headline":
+        tx_headline_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "long":
         long_golden()
     else:

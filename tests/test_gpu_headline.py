@@ -223,8 +223,18 @@ def test_pipelined_equals_unpipelined_ragged(ctx, oracle, cfg):
         assert got[0].shape[1] == 0
         exp, got = np.concatenate(exp, axis=1), np.concatenate(got, axis=1)
         assert exp.shape[1] == 4 and np.array_equal(exp, got), cfg
-        # and against the oracle chain for one stream
-        y, ss = oracle.decimators(0).decimate(log2, 2, 16, xs[0])
+        # and against the oracle chain (decimator -> framer fed call by call with the same stamps -> encoder) for every stream
+        for s in range(S):
+            od, fr, pos, ofr = oracle.decimators(0), oracle.framer(nb_fec_blocks=R), 0, []
+            for i in range(4):
+                y, ss = od.decimate(log2, 2, 16, xs[s, cuts[i]:cuts[i + 1]])
+                fr.s.tv_sec, fr.s.tv_usec = 10 + i, 5 * i
+                ofr.append(fr.write(y))
+            ofr = np.concatenate(ofr)
+            assert ss == 16 and ofr.shape[0] == 4
+            for f in range(4):
+                assert np.array_equal(got[s, f, :128], ofr[f]), (cfg, s, f, "frame vs oracle")
+                assert np.array_equal(got[s, f, 128:], oracle.frame_encode(ofr[f], R)), (cfg, s, f, "FEC vs oracle")
     finally:
         ctx.set_option("decim_path", "auto")
         ctx.set_option("mfma_span", 0)
@@ -244,3 +254,139 @@ def test_pipelined_reconfigure_needs_a_flush(ctx):
     rx.process(x[2 * 16129 * 16:], 3, 4)
     out = rx.flush()
     assert out.shape[1:] == (1, 136, 512)
+
+
+# ---------------------------------------------------------------- the benchmarked Tx launch
+def _tx_input(ctx):
+    import headline_inputs as hi
+
+    x, _ = _bank("bank8")
+    rxf, keep = hi.tx_received_frames(ctx, x, H["meta"])
+    del x
+    return rxf, keep
+
+
+@pytest.mark.parametrize("max_rows,dec_path", [(32, "syndrome"), (128, "syndrome"), (128, "dense")])
+def test_headline_tx_bank_8_x_128_frames(ctx, max_rows, dec_path):
+    """bench.py's configs[3] step, exactly: tx.process(rxf) on 8 streams x 128 frames (config 3's frames of the bank8 run, a
+    distinct random 24-of-160 loss pattern per frame), with bench.py's dec_max_rows = 32 (no fallback launches), with the default
+    128, and through the dense decoder; whole outputs against digests made from the oracle's decode + the REFERENCE's
+    interpolate16_cen (headline_golden.json: tx_bank8).  The decoder alone against the payload digests as well."""
+    import sdrdaemon_amd as sd
+
+    T = H["tx_bank8"]
+    rxf, keep = _tx_input(ctx)
+    S, F = rxf.shape[0], rxf.shape[1]
+    assert (S, F) == (len(T["seeds"]), T["frames"]) and len({k.tobytes() for k in keep}) == S * F
+    ctx.set_option("dec_max_rows", max_rows)
+    ctx.set_option("dec_path", dec_path)
+    before = ctx.counter("dec_rows_exceeded")
+    try:
+        tx = sd.TxPipe(ctx, S, T["log2interp"])
+        iq = tx.process(rxf)
+        ctx.synchronize()
+        assert iq.shape == (S, (F * 16129) << T["log2interp"], 2)
+        for s in range(S):
+            assert _sha(iq[s]) == T["iq_sha256"][s], ("tx output of stream", s)
+        del iq, tx
+        pay = sd.fec_decode_frames(ctx, rxf.reshape(S * F, 128, 512))
+        ctx.synchronize()
+        pay = pay[0] if isinstance(pay, tuple) else pay
+        pay = pay.reshape(S, F, -1)
+        for s in range(S):
+            assert _sha(pay[s]) == T["payload_sha256"][s], ("decoded payload of stream", s)
+        assert ctx.counter("dec_rows_exceeded") == before
+    finally:
+        ctx.set_option("dec_max_rows", 128)
+        ctx.set_option("dec_path", "syndrome")
+
+
+@pytest.mark.parametrize("dec_path", ["syndrome", "dense"])
+def test_dec_max_rows_is_checked_on_the_device(ctx, oracle, dec_path):
+    """dec_max_rows is a promise; a frame that breaks it (33 recovery blocks under dec_max_rows = 32) is left as received --
+    missing originals read zero, like an undecodable frame -- and COUNTED (sdrhip_ctx_get_counter), never half repaired and
+    never silently; the same batch under dec_max_rows = 128 decodes completely."""
+    import sdrdaemon_amd as sd
+
+    rs = np.random.RandomState(5)
+    frames = rs.randint(0, 256, (3, 128, 512)).astype(np.uint8)
+    frames[:, :, 0:2] = 0
+    frames[:, :, 2] = np.arange(128)
+    frames[:, :, 3] = 0
+    allb = np.stack([np.concatenate([frames[f], oracle.frame_encode(frames[f], 40)]) for f in range(3)])
+    lost = [sorted(rs.choice(np.arange(1, 128), n, replace=False).tolist()) for n in (32, 33, 24)]  # frame 1 breaks the promise
+    keeps = [[i for i in range(168) if i not in set(l)][:128] for l in lost]
+    rx = np.stack([allb[f][keeps[f]] for f in range(3)])
+    ctx.set_option("dec_path", dec_path)
+    try:
+        ctx.set_option("dec_max_rows", 32)
+        c0 = ctx.counter("dec_rows_exceeded")
+        pay, b0 = sd.fec_decode_frames(ctx, rx, want_block0=True)
+        assert ctx.counter("dec_rows_exceeded") == c0 + 1
+        for f in (0, 2):
+            assert np.array_equal(pay[f].reshape(127, 508), frames[f, 1:, 4:]), f
+        exp = frames[1, 1:, 4:].copy()
+        exp[[i - 1 for i in lost[1]]] = 0
+        assert np.array_equal(pay[1].reshape(127, 508), exp), "a frame beyond the promise keeps what was received, holes = 0"
+        ctx.set_option("dec_max_rows", 128)
+        pay, b0 = sd.fec_decode_frames(ctx, rx, want_block0=True)
+        assert ctx.counter("dec_rows_exceeded") == c0 + 1
+        for f in range(3):
+            assert np.array_equal(pay[f].reshape(127, 508), frames[f, 1:, 4:]), f
+    finally:
+        ctx.set_option("dec_max_rows", 128)
+        ctx.set_option("dec_path", "syndrome")
+
+
+def test_pipelined_many_calls_wrap_the_frame_window(ctx, oracle):
+    """24 pipelined calls of varying size -- enough to exceed the frame area (cap_frames = 4 x (frames of the
+    biggest call so far + 1)) several times, to wrap it while frames wait for delivery (wrap_hits_late -> a new area, the old
+    one handed over as old_work) and to alternate the two stream-order buffers well beyond 4 calls; an empty call in the middle
+    delivers like any other.  Every delivered frame against the unpipelined pipe AND the oracle chain."""
+    import sdrdaemon_amd as sd
+
+    log2, R, S = 4, 32, 2
+    ctx.set_option("decim_path", "mfma")
+    ctx.set_option("mfma_span", 64 << log2)
+    try:
+        rs = np.random.RandomState(17)
+        sizes = [int(v) << log2 for v in rs.choice([700, 16129, 20000, 40000, 3 * 16129, 90000, 5000, 64516], 24)]
+        sizes[7] = 0            # an empty call: delivers call 6's frames
+        sizes[15] = 150000 << log2  # a big one: grows the area while call 14's frames wait
+        n = sum(sizes)
+        xs = np.stack([signals.noise(n, 80 + s) for s in range(S)])
+        a = sd.RxPipe(ctx, S, log2decim=log2, nb_fec=R)
+        p = sd.RxPipe(ctx, S, log2decim=log2, nb_fec=R, pipelined=True)
+        pos, prev = 0, None
+        got_all = []
+        for i, c in enumerate(sizes):
+            seg = xs[:, pos:pos + c]
+            pos += c
+            e = a.process(seg, 100 + i, 3 * i) if c else np.zeros((S, 0, 128 + R, 512), np.uint8)
+            g = p.process(seg, 100 + i, 3 * i)
+            if prev is not None:
+                assert g.shape == prev.shape and np.array_equal(g, prev), ("call", i)
+            else:
+                assert g.shape[1] == 0
+            got_all.append(g)
+            prev = e
+        last = p.flush()
+        assert np.array_equal(last, prev)
+        got_all.append(last)
+        got = np.concatenate(got_all, axis=1)
+        assert got.shape[1] == (n >> log2) // 16129
+        for s in range(S):
+            od, fr, ofr, q = oracle.decimators(0), oracle.framer(nb_fec_blocks=R), [], 0
+            for i, c in enumerate(sizes):
+                y, _ = od.decimate(log2, 2, 16, xs[s, q:q + c])
+                q += c
+                fr.s.tv_sec, fr.s.tv_usec = 100 + i, 3 * i
+                ofr.append(fr.write(y))
+            ofr = np.concatenate(ofr)
+            assert ofr.shape[0] == got.shape[1]
+            assert np.array_equal(got[s, :, :128], ofr), ("frames vs oracle", s)
+            for f in range(0, ofr.shape[0], 7):
+                assert np.array_equal(got[s, f, 128:], oracle.frame_encode(ofr[f], R)), (s, f)
+    finally:
+        ctx.set_option("decim_path", "auto")
+        ctx.set_option("mfma_span", 0)

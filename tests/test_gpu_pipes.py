@@ -353,3 +353,45 @@ def test_tx_pipe_live_interp_change(ctx, oracle):
         rxb = allb[[i for i in range(136) if i not in (3, 77)][:128]]  # two originals lost
         got = tx.process(rxb[None])
         assert np.array_equal(got, ou.interpolate(log2, x[f * 16129:(f + 1) * 16129])), (f, log2)
+
+
+def test_rx_meta_block_is_the_reference_s_literal_record_when_the_clock_does_not_advance(ctx, oracle):
+    """the product stamps the frames a call opens from the sample clock (tv + floor(p * 10^6 / rate)); the reference
+    stamps them with gettimeofday as they open (UDPSinkFEC.cpp:90-109).  With sample_rate = 0 the clock does not advance and the
+    record must be the reference's literal one: every frame a call opens carries (tv_sec, tv_usec) as given, CRC-32 over the
+    first 20 bytes -- checked against the oracle framer in its literal mode (stamp_from_samples = 0), several frames per call."""
+    import zlib
+
+    import sdrdaemon_amd as sd
+
+    x = signals.noise((3 * 16129 + 100) << 2, 91)
+    rx = sd.RxPipe(ctx, 1, log2decim=2, nb_fec=8, center_frequency_khz=144000, sample_rate=0)
+    got = rx.process(x, tv_sec=1234567, tv_usec=765432)
+    y, ss = oracle.decimators(0).decimate(2, 2, 16, x)
+    fr = oracle.framer(nb_fec_blocks=8, center_frequency_khz=144000, sample_rate=0, tv_sec=1234567, tv_usec=765432, stamp_from_samples=0)
+    exp = fr.write(y)
+    assert got.shape[0] == exp.shape[0] == 3
+    for f in range(3):
+        assert np.array_equal(got[f, :128], exp[f]), f
+        rec = got[f, 0, 4:28].tobytes()
+        assert int.from_bytes(rec[12:16], "little") == 1234567 and int.from_bytes(rec[16:20], "little") == 765432
+        assert int.from_bytes(rec[20:24], "little") == zlib.crc32(rec[:20])
+
+
+def test_last_plan_reports_no_cascade_after_a_filterless_call(ctx):
+    """sdrhip_decimators_last_plan after decimate1 / decimate4_inf / an empty call is path 0, not the previous plan"""
+    import sdrdaemon_amd as sd
+
+    d = sd.Decimators(ctx, 1, sd.HB_EO1)
+    x = signals.noise(1 << 14, 3)
+    d.decimate(4, 2, 16, x)
+    assert d.last_plan()["path"] == "valu"
+    d.decimate(2, 0, 16, x)
+    assert d.last_plan()["path"] is None
+    d.decimate(4, 2, 16, x)
+    assert d.last_plan()["path"] == "valu"
+    d.decimate(0, 2, 16, x)
+    assert d.last_plan()["path"] is None
+    d.decimate(4, 2, 16, x)
+    d.decimate(4, 2, 16, x[:3])
+    assert d.last_plan()["path"] is None

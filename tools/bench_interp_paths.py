@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""VALU vs matrix-core interpolator kernels on the GPU box (hipEvent kernel-class timers).
-usage: python tools/bench_interp_paths.py [path:span:log2interp] [log2 outputs per stream, default 25] [streams, default 8]"""
+"""Interpolator kernels on the GPU box (hipEvent kernel-class timers): K5 (valu), K5w (wave), K5m (mfma, when built in).
+usage: python tools/bench_interp_paths.py [path:span:log2interp] [log2 outputs per stream, default 25] [streams, default 8]
+       PATHS=valu:0,wave:0,wave:1024 LS=4,5 python tools/bench_interp_paths.py ..."""
 import os
 import sys
 import time
@@ -35,13 +36,15 @@ def timed(fn, reps=int(os.environ.get("REPS", "30")), preroll_s=0.25):
     return ms / max(cnt, 1)
 
 
-for L in (4, 3, 2) if ONLY is None else (int(ONLY[2]),):
+PATHS = [(a.split(":")[0], int(a.split(":")[1])) for a in os.environ.get("PATHS", "valu:0,wave:0").split(",")]
+LS = [int(v) for v in os.environ.get("LS", "4,3,2").split(",")]
+for L in LS if ONLY is None else (int(ONLY[2]),):
     n_out = 1 << LOGN
     n = n_out >> L
     x = torch.randint(-32768, 32768, (S, n, 2), generator=g, device=dev, dtype=torch.int16)
     out = torch.empty((S, n_out, 2), dtype=torch.int16, device=dev)
     ref = None
-    for path, span in ((("valu", 0), ("mfma", 0), ("mfma", 1024), ("mfma", 2048), ("mfma", 8192)) if ONLY is None else ((ONLY[0], int(ONLY[1])),)):
+    for path, span in (PATHS if ONLY is None else ((ONLY[0], int(ONLY[1])),)):
         ctx.set_option("interp_path", path)
         ctx.set_option("interp_span", span)
         d = sd.Interpolators(ctx, S)

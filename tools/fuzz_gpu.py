@@ -190,6 +190,11 @@ while time.time() - t0 < budget:
         x = signals.noise(F * 16129, int(rs.randint(1 << 30)))
         frames = orc.framer(nb_fec_blocks=R).write(x)
         rxb = np.zeros((F, 128, 512), np.uint8)
+        # dec_max_rows: the sender's fecblk, the default (128), or a promise some frames BREAK (they must come out as received,
+        # holes = 0, and be counted: sdrhip_ctx_get_counter)
+        max_rows = int(rs.choice([R, R, 128, max(1, R // 4)]))
+        ctx.set_option("dec_max_rows", max_rows)
+        exceeded0, n_exceed = ctx.counter("dec_rows_exceeded"), 0
         for f in range(F):
             allb = np.concatenate([frames[f], orc.frame_encode(frames[f], R)])
             nlost = int(rs.randint(0, R + 1))
@@ -207,6 +212,13 @@ while time.time() - t0 < budget:
                         hole[b - 1] = allb[b, 4:]
                 x[f * 16129:(f + 1) * 16129] = hole.reshape(-1).view(np.int16).reshape(-1, 2)
                 keep = keep + [keep[0]] * (128 - len(keep))
+            elif sum(1 for i in keep if i >= 128) > max_rows:
+                n_exceed += 1
+                hole = np.zeros((127, 508), np.uint8)
+                for b in keep:
+                    if 1 <= b < 128:
+                        hole[b - 1] = allb[b, 4:]
+                x[f * 16129:(f + 1) * 16129] = hole.reshape(-1).view(np.int16).reshape(-1, 2)
             rxb[f] = allb[keep]
         tx = sd.TxPipe(ctx, 1, L)
         if rs.rand() < 0.4:  # frames resident on the device: the planning kernel reads the block indices from the headers
@@ -217,6 +229,8 @@ while time.time() - t0 < budget:
             y = yt.cpu().numpy().reshape(-1, 2)
         else:
             y = np.asarray(tx.process(rxb)).reshape(-1, 2)
-        assert np.array_equal(y, orc.interpolators().interpolate(L, x)), ("tx", it, F, R, L)
+        assert np.array_equal(y, orc.interpolators().interpolate(L, x)), ("tx", it, F, R, L, max_rows)
+        assert ctx.counter("dec_rows_exceeded") - exceeded0 == n_exceed, ("tx dec_max_rows counter", it, max_rows, n_exceed)
+        ctx.set_option("dec_max_rows", 128)
     stats[what] += 1
 print("fuzz OK: %d iterations in %.0f s: %s" % (it, time.time() - t0, stats))
