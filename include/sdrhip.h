@@ -72,7 +72,7 @@ int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
 /* Kernel-path knobs for tests and tools (production code never needs them).  The defaults are read from the environment
  * ONCE, when the context is created (SDRHIP_DECIM_PATH, SDRHIP_MFMA_SPAN, SDRHIP_MFMA_MIN, SDRHIP_INTERP_PATH,
  * SDRHIP_INTERP_SPAN, SDRHIP_RX_FUSED); keys: "decim_path" = auto | valu | mfma, "mfma_span" / "mfma_min" / "interp_span" =
- * decimal sample counts, "interp_path" = valu | mfma, "rx_fused" = 0 | 1, "dec_path" = syndrome | dense.  Every setting
+ * decimal sample counts, "interp_path" = auto | wave | valu | mfma (wave = K5w, the default from interpolate4 up; valu = K5), "rx_fused" = 0 | 1, "dec_path" = syndrome | dense.  Every setting
  * computes the same bytes.  One knob is a promise, not a path: "dec_max_rows" = 1..128 (default 128), the most recovery
  * blocks a received frame can carry (the sender's fecblk, known from the meta block); <= 32 spares the batched decoder the
  * launches of its fallback kernel.  The promise is checked on the device: a frame that carries MORE recovery blocks than

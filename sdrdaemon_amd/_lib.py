@@ -15,7 +15,8 @@ except Exception:  # pragma: no cover - torch is optional for pure host-pointer 
     torch = None
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsdrhip.so")
+# SDRHIP_LIB_PATH: a variant build of the same library (tools/experiments_*: kernel A / B runs); there is still no fallback
+LIB_PATH = os.environ.get("SDRHIP_LIB_PATH") or os.path.join(HERE, "libsdrhip.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 FC_INF, FC_SUP, FC_CEN = 0, 1, 2

@@ -42,7 +42,7 @@ template <int L> __global__ __launch_bounds__(WNT) void interp_wave_kernel(Inter
 
 template <int L> hipError_t launch_w(const InterpArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((interp_wave_kernel<L>), dim3(a.nseg, a.nstreams), dim3(WNT), 0, stream, a);
+    hipLaunchKernelGGL((interp_wave_kernel<L>), dim3(a.nseg, a.nstreams), dim3(WNT), a.dyn_lds, stream, a);
     return hipGetLastError();
 }
 
@@ -65,26 +65,16 @@ void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_s
     *nseg = (int)((nsub + per - 1) / per);
 }
 
-// K5w: blocks of 128 inputs; the segments are sized so that the launch is a whole number of rounds of the chip's wave slots
-// (waves_per_cu resident one-wave workgroups per CU), at least 8 blocks each (the warm-up of a segment is half a block)
+// K5w: blocks of 128 inputs, segments of at most 2 x WPAIRS = 16 blocks (the wave parks its whole segment's input in registers at
+// its start), an even number of them (the input comes back a PAIR of blocks at a time; an odd rest runs the guarded path)
 void plan_interpolate_wave(int log2interp, size_t n_in, int nstreams, int n_cu, size_t seg_override, int *nsub_per_seg, int *nseg)
 {
-    (void)log2interp;
+    (void)log2interp; (void)nstreams; (void)n_cu;
     size_t nsub = (n_in + WB - 1) / WB;
     if (nsub == 0) nsub = 1;
-    size_t per;
-    if (seg_override) {
-        per = (seg_override + WB - 1) / WB;
-    } else {
-        const size_t slots = (size_t)n_cu * 16;
-        const size_t total = nsub * (size_t)nstreams;
-        size_t rounds = (total / 16 + slots - 1) / slots; // rounds of segments of ~16 blocks
-        if (rounds == 0) rounds = 1;
-        const size_t per_stream = (rounds * slots + nstreams - 1) / nstreams; // segments per stream
-        per = (nsub + per_stream - 1) / per_stream;
-        if (per < 8) per = 8;
-    }
-    if (per > nsub) per = nsub;
+    size_t per = seg_override ? (seg_override + WB - 1) / WB : 2 * WPAIRS;
+    if (per > 2 * WPAIRS) per = 2 * WPAIRS;
+    if (per > 1) per &= ~(size_t)1;
     if (per < 1) per = 1;
     *nsub_per_seg = (int)per;
     *nseg = (int)((nsub + per - 1) / per);

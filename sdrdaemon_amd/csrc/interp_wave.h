@@ -11,8 +11,6 @@
 //    output instead of 16 adds + 16 multiply-adds (the raw samples are int16; every later stage sees 19-bit values);
 //  * the last stage multiplies by 8 x tap: (acc >> 13) & 0xffff is then the HIGH half of the accumulator, and one v_perm_b32 both
 //    shifts and packs I/Q (the truncation to int16 drops everything above bit 28 anyway);
-//  * the 32-entry history of a stage buffer is rewritten from the PRODUCER's registers after the consumer is done (two
-//    ds_write_b128 on four lane pairs) instead of an LDS read -> wait -> write round trip per invocation.
 #ifndef SDRHIP_INTERP_WAVE_H
 #define SDRHIP_INTERP_WAVE_H
 #include "interp_body.h"
@@ -20,12 +18,18 @@
 namespace sdrhip {
 namespace {
 
+#ifndef W_ABL
+#define W_ABL 0 // timing experiments (WRONG results): 1 no global stores, 2 no FIR arithmetic in stages >= 1, 4 none in stage 0, 8 stores to one cached slot per wave, 16 non-temporal stores, 64 no input loads
+#endif
 constexpr int WNT = 64;          // one wave
 constexpr int WB = 128;          // inputs per block
 constexpr int WCAP = 256;        // fresh entries a stage buffer (s >= 1) holds
 constexpr int WSTR = HIST + WCAP; // 288 dwords = 72 sixteen-byte slots = 8 mod 16: I / Q lane pairs of a ds_read_b128 group hit distinct banks
-constexpr int W0HIST = 16;       // packed stage-0 plane: 16 dwords (32 entries) of history + 64 fresh
-constexpr int W0STR = 96;        // ... padded to 48 eight-byte slots = 16 mod 32: the I / Q lanes of a ds_read_b64 group hit distinct banks
+constexpr int WPAIRS = 8;        // a segment's whole input (<= 2 x WPAIRS blocks) is loaded at the wave's start and parked in 4 x WPAIRS AGPRs
+constexpr int WG = 2;            // blocks staged at a time: one dwordx4 load per lane covers a PAIR of blocks (256 samples)
+constexpr int W0HIST = 16;       // packed stage-0 plane: 16 dwords (32 entries) of history + WG x 64 fresh
+constexpr int W0STR = 32 + 64 * WG; // ... padded to 16 mod 32 eight-byte slots: the I / Q lanes of a ds_read_b64 group hit distinct banks
+static_assert(W0STR % 64 == 32 && W0STR >= W0HIST + 64 * WG, "stage-0 plane stride");
 
 typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
 
@@ -39,6 +43,16 @@ template <int NS_> struct WGeo {
 __host__ __device__ constexpr int h64(int d) { return d < 16 ? T64[d] : T64[31 - d]; }
 __host__ __device__ constexpr unsigned tap_pair(int e) { return ((unsigned)h64(2 * e + 1) & 0xffffu) | ((unsigned)h64(2 * e) << 16); }
 
+// The lanes of the wave hand data to EACH OTHER through LDS.  The hardware executes a wave's LDS operations in order, so no
+// instruction is needed -- but the compiler reasons per thread: it may move a lane's read above a write of the same lane that
+// it can prove disjoint (and did: the second half of a stage's output write sank below the next stage's window reads).  A
+// wavefront-scope fence + wave barrier pins the order of the accesses; neither emits an instruction.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ int wdot2(unsigned a, unsigned taps, int acc)
 {
     typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -46,12 +60,12 @@ __device__ __forceinline__ int wdot2(unsigned a, unsigned taps, int acc)
 }
 
 // stage 0 (order 64) on packed int16 planes: `valid` inputs of the block -> 2 * valid entries at the start of stage 1's buffer
-template <class G> __device__ __forceinline__ void wstage0(int *lds, int lane, int valid, int (&o)[8])
+template <class G, bool FULL> __device__ __forceinline__ void wstage0(int *lds, int lane, int blk, int valid, int (&o)[8])
 {
     const int j = lane >> 1, comp = lane & 1, m0 = 4 * j;
-    if (m0 >= valid) return;
-    // window dword t <-> entries u[m0 - 32 + 2t], u[m0 - 32 + 2t + 1]
-    const unsigned *pl = reinterpret_cast<const unsigned *>(lds) + comp * W0STR + 2 * j;
+    if (!FULL && m0 >= valid) return;
+    // window dword t <-> entries u[m0 - 32 + 2t], u[m0 - 32 + 2t + 1] of block blk of the group
+    const unsigned *pl = reinterpret_cast<const unsigned *>(lds) + comp * W0STR + 64 * blk + 2 * j;
     unsigned W[18];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
@@ -62,6 +76,9 @@ template <class G> __device__ __forceinline__ void wstage0(int *lds, int lane, i
 #pragma unroll
     for (int t = 1; t < 18; ++t) A[t] = __builtin_amdgcn_alignbit(W[t], W[t - 1], 16);
     int acc[4] = {0, 0, 0, 0};
+#if W_ABL & 4
+    acc[0] = (int)(A[1] ^ A[16]); acc[1] = (int)(W[0] ^ W[17]); acc[2] = (int)(A[2] ^ A[17]); acc[3] = (int)(W[3] ^ W[12]);
+#else
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         acc[0] = wdot2(A[16 - e], tap_pair(e), acc[0]);
@@ -69,6 +86,7 @@ template <class G> __device__ __forceinline__ void wstage0(int *lds, int lane, i
         acc[2] = wdot2(A[17 - e], tap_pair(e), acc[2]);
         acc[3] = wdot2(W[17 - e], tap_pair(e), acc[3]);
     }
+#endif
     // v[2m] = u[m - 16]: entries 16 .. 19 of the window
     o[0] = (int)(short)(W[8] & 0xffffu); o[2] = (int)W[8] >> 16; o[4] = (int)(short)(W[9] & 0xffffu); o[6] = (int)W[9] >> 16;
     o[1] = acc[0] >> 13; o[3] = acc[1] >> 13; o[5] = acc[2] >> 13; o[7] = acc[3] >> 13;
@@ -78,11 +96,11 @@ template <class G> __device__ __forceinline__ void wstage0(int *lds, int lane, i
 }
 
 // a middle stage (1 <= S < NS - 1): `valid` inputs at in_off of its buffer -> 2 * valid entries at the start of the next buffer
-template <class G, int S> __device__ __forceinline__ void wstage(int *lds, int lane, int in_off, int valid, int (&o)[8])
+template <class G, int S, bool FULL> __device__ __forceinline__ void wstage(int *lds, int lane, int in_off, int valid, int (&o)[8])
 {
     constexpr int O = stage_order(S), K = O / 4, S2 = O / 2, R = 4;
     const int j = lane >> 1, comp = lane & 1, m0 = j * R;
-    if (m0 >= valid) return;
+    if (!FULL && m0 >= valid) return;
     const int *pl = lds + G::base(S) + comp * WSTR + HIST + in_off + m0 - S2; // window x <-> u[m0 - O/2 + x]
     int w[R + S2];
 #pragma unroll
@@ -93,8 +111,12 @@ template <class G, int S> __device__ __forceinline__ void wstage(int *lds, int l
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int acc = 0;
+#if W_ABL & 2
+        acc = w[r + 1] ^ w[r + S2];
+#else
 #pragma unroll
         for (int i = 0; i < K; ++i) acc = mad24(w[r + 1 + i] + w[r + S2 - i], tap(O, i), acc);
+#endif
         o[2 * r] = w[r + K]; // u[m - O/4]
         o[2 * r + 1] = acc >> 13;
     }
@@ -104,11 +126,11 @@ template <class G, int S> __device__ __forceinline__ void wstage(int *lds, int l
 }
 
 // the last stage: both components per lane, taps x 8 (the int16 result is the accumulator's high half), 2 x 16-byte stores
-template <class G, int S> __device__ __forceinline__ void wstage_last(int *lds, int lane, int in_off, int valid, const IOut &oc)
+template <class G, int S, bool FULL> __device__ __forceinline__ void wstage_last(int *lds, int lane, int in_off, int valid, const IOut &oc)
 {
     constexpr int O = stage_order(S), K = O / 4, S2 = O / 2, R = 4;
     const int m0 = lane * R;
-    if (m0 >= valid || !oc.store) return;
+    if (!FULL && (m0 >= valid || !oc.store)) return;
     int ev[2][R], od[2][R];
 #pragma unroll
     for (int comp = 0; comp < 2; ++comp) {
@@ -122,8 +144,12 @@ template <class G, int S> __device__ __forceinline__ void wstage_last(int *lds, 
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             int acc = 0;
+#if W_ABL & 2
+            acc = w[r + 1] ^ w[r + S2];
+#else
 #pragma unroll
             for (int i = 0; i < K; ++i) acc = mad24(w[r + 1 + i] + w[r + S2 - i], 8 * tap(O, i), acc);
+#endif
             ev[comp][r] = w[r + K];
             od[comp][r] = acc; // (acc >> 13) & 0xffff == bits 16..31 of 8 * sum
         }
@@ -137,9 +163,19 @@ template <class G, int S> __device__ __forceinline__ void wstage_last(int *lds, 
     size_t idx = oc.out_pos + 2 * (size_t)m0; // chain output index
     if (oc.stuff64) idx = (idx >> 5) * 64 + (idx & 31);
     unsigned *dst = oc.out + idx;
-    if (m0 + R <= valid) {
+#if W_ABL & 8
+    dst = oc.out + ((size_t)blockIdx.x * 512 + 2 * (size_t)m0);
+#endif
+    if (FULL || m0 + R <= valid) {
+#if W_ABL & 1
+        asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(pk[4]), "v"(pk[5]), "v"(pk[6]), "v"(pk[7]), "v"(dst));
+#elif W_ABL & 16
+        __builtin_nontemporal_store((uint4_t){pk[0], pk[1], pk[2], pk[3]}, reinterpret_cast<uint4_t *>(dst));
+        __builtin_nontemporal_store((uint4_t){pk[4], pk[5], pk[6], pk[7]}, reinterpret_cast<uint4_t *>(dst + 4));
+#else
         *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
         *reinterpret_cast<uint4_t *>(dst + 4) = (uint4_t){pk[4], pk[5], pk[6], pk[7]};
+#endif
         if (oc.stuff64) {
             *reinterpret_cast<uint4_t *>(dst + 32) = (uint4_t){0u, 0u, 0u, 0u};
             *reinterpret_cast<uint4_t *>(dst + 36) = (uint4_t){0u, 0u, 0u, 0u};
@@ -154,45 +190,47 @@ template <class G, int S> __device__ __forceinline__ void wstage_last(int *lds, 
     }
 }
 
-// history of stage S (S >= 1) after its n fresh entries were consumed: entries [n - 32, n) -> [0, 32).  The producer's lane
-// pairs still hold them (o[0..7] = entries 8j .. 8j+7): straight from the registers when whole lanes line up, through LDS
-// otherwise (one instruction each: the whole wave reads before it writes, source and destination may overlap)
-template <class G, int S> __device__ __forceinline__ void whist(int *lds, int lane, int n, const int (&o)[8])
+// history of stage S (S >= 1) after its n fresh entries were consumed: entries [n - 32, n) -> [0, 32) of both planes, one
+// ds_read_b32 + one ds_write_b32 of the whole wave (the wave reads before it writes: source and destination may overlap).
+// (Writing them from the producer's registers instead -- they are still there -- costs two ds_write_b128 per invocation, and an
+// LDS store is priced by instruction, not by active lane: 26 cycles of the CU's LDS pipe against 6, and the LDS pipe is one
+// of the three resources this kernel keeps ~50 % busy: tools/store_lds_mix.hip.)
+template <class G, int S> __device__ __forceinline__ void whist(int *lds, int lane, int n)
 {
-    if (n >= HIST && (n & 7) == 0) {
-        const int j = lane >> 1, comp = lane & 1;
-        const int e0 = 8 * j - (n - HIST);
-        if (e0 >= 0 && 8 * j < n) {
-            int *pl = lds + G::base(S) + comp * WSTR + e0;
-            *reinterpret_cast<int4_t *>(pl) = (int4_t){o[0], o[1], o[2], o[3]};
-            *reinterpret_cast<int4_t *>(pl + 4) = (int4_t){o[4], o[5], o[6], o[7]};
-        }
-    } else {
-        int *pl = lds + G::base(S) + (lane >> 5) * WSTR;
-        const int e = lane & 31;
-        const int v = pl[n + e]; // = fresh entry n - 32 + e (or history entry n + e when n < 32)
-        pl[e] = v;
-    }
+    int *pl = lds + G::base(S) + (lane >> 5) * WSTR;
+    const int e = lane & 31;
+    const int v = pl[n + e]; // = fresh entry n - 32 + e (or history entry n + e when n < 32)
+    wave_sync();
+    pl[e] = v;
 }
 
-// depth-first walk: stage S consumes `valid` inputs at in_off of its buffer
-template <class G, int S> __device__ __forceinline__ void wdescend(int *lds, int lane, int in_off, int valid, IOut &oc)
+// FULL: a whole block with its stores (valid = 128 per stage invocation, 256 in the last stage): every guard is a compile-time
+// constant and the walk is straight-line code apart from the LDS-only history writes -- which is what lets hipcc count the
+// block's eight stores behind the prefetch load exactly (s_waitcnt vmcnt(8) instead of a drain of the stores, see the loop)
+template <class G, int S, bool FULL> __device__ __forceinline__ void wdescend(int *lds, int lane, int in_off, int valid_rt, IOut &oc)
 {
+    const int valid = FULL ? (S == G::NS - 1 ? WCAP : WB) : valid_rt;
     if constexpr (S == G::NS - 1) {
-        wstage_last<G, S>(lds, lane, in_off, valid, oc);
-        if (oc.store) oc.out_pos += 2 * (size_t)valid;
+        wstage_last<G, S, FULL>(lds, lane, in_off, valid, oc);
+        if (FULL || oc.store) oc.out_pos += 2 * (size_t)valid;
     } else {
-        int o[8]; // (read back by whist only on the lanes that computed them)
-        if constexpr (S == 0) wstage0<G>(lds, lane, valid, o);
-        else wstage<G, S>(lds, lane, in_off, valid, o);
+        int o[8];
+        if constexpr (S == 0) wstage0<G, FULL>(lds, lane, in_off, valid, o); // (stage 0: in_off = the block's index in its group)
+        else wstage<G, S, FULL>(lds, lane, in_off, valid, o);
+        wave_sync(); // the stage's outputs, written by all lanes, are read by other lanes next
         const int n = 2 * valid;
         if constexpr (S + 1 == G::NS - 1) {
-            wdescend<G, S + 1>(lds, lane, 0, n, oc);
+            wdescend<G, S + 1, FULL>(lds, lane, 0, n, oc);
+        } else if constexpr (FULL) {
+            wdescend<G, S + 1, true>(lds, lane, 0, WB, oc);
+            wdescend<G, S + 1, true>(lds, lane, WB, WB, oc);
         } else {
-            wdescend<G, S + 1>(lds, lane, 0, n < WB ? n : WB, oc);
-            if (n > WB) wdescend<G, S + 1>(lds, lane, WB, n - WB, oc);
+            wdescend<G, S + 1, false>(lds, lane, 0, n < WB ? n : WB, oc);
+            if (n > WB) wdescend<G, S + 1, false>(lds, lane, WB, n - WB, oc);
         }
-        whist<G, S + 1>(lds, lane, n, o);
+        wave_sync(); // (the consumers' reads of the old history stay in front of its rewrite)
+        whist<G, S + 1>(lds, lane, n);
+        wave_sync();
     }
 }
 
@@ -212,6 +250,14 @@ template <class G, int S = 0> __device__ __forceinline__ void wstate_store(const
 }
 
 // one segment (seg of a.nseg, a.nsub_per_seg blocks of 128 inputs each) of one stream, on one wave; L >= 2
+//
+// WHERE THE INPUT LOADS GO decides this kernel (tools/store_load_mix.hip, tools/experiments_r04/): a streaming store pattern
+// that runs 5.7 TB/s on its own drops to 3.5 TB/s when 6 % of the bytes are loads issued 512 B at a time between the stores --
+// whether the loads are awaited or not, hit in the cache or not, even when OTHER waves issue them.  Clustered, they are almost
+// free: a wave's whole input as 1 KiB loads back to back at its start costs 10 %.  So a wave loads the input of its whole
+// segment (<= 16 blocks = 8 KiB: eight global_load_dwordx4) in front of everything else, parks it in 32 accumulation registers
+// (nothing else uses them, so nothing moves them) and issues nothing but stores from then on; a pair of blocks at a time comes
+// back through v_accvgpr_read, is de-interleaved into packed I / Q pairs and staged in LDS.
 template <int L> __device__ __forceinline__ void interp_wave_segment(const InterpArgs &a, int seg, int stream, int *lds)
 {
     constexpr int NS = (L == 6) ? 5 : L;
@@ -224,60 +270,105 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
     size_t seg_end = seg_start + seg_len;
     if (seg_end > a.n_in) seg_end = a.n_in;
 
+    unsigned *p0 = reinterpret_cast<unsigned *>(lds);
+    // ---- the segment's whole blocks, pair by pair, into AGPRs (pairs beyond the segment: not loaded, never read)
+    const bool al16 = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+    const int npairs = al16 ? (int)((seg_end - seg_start) / (2 * WB) < (size_t)WPAIRS ? (seg_end - seg_start) / (2 * WB) : (size_t)WPAIRS) : 0;
+    unsigned A[4 * WPAIRS];
+    {
+        uint4_t v[WPAIRS];
+#pragma unroll
+        for (int p = 0; p < WPAIRS; ++p) { // all of them back to back: ONE cluster of reads per wave
+            v[p] = (uint4_t){0u, 0u, 0u, 0u};
+#if W_ABL & 64
+            v[p].x = (unsigned)(p + lane);
+#else
+            if (p < npairs) v[p] = SDRHIP_STREAM_LOAD(reinterpret_cast<const uint4_t *>(in + seg_start + (size_t)p * 2 * WB + 4 * lane));
+#endif
+        }
+#pragma unroll
+        for (int p = 0; p < WPAIRS; ++p)
+            asm volatile("v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
+                         : "=a"(A[4 * p]), "=a"(A[4 * p + 1]), "=a"(A[4 * p + 2]), "=a"(A[4 * p + 3]) : "v"(v[p].x), "v"(v[p].y), "v"(v[p].z), "v"(v[p].w));
+    }
+
     const int32_t *stc = a.state_cur + (size_t)stream * INT_STATE_WORDS;
     wstate_load<G>(lds, lane, stc, seg != 0);
+    wave_sync();
 
     IOut oc;
     oc.out = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
     oc.stuff64 = (L == 6);
     oc.out_pos = seg_start << NS;
+    oc.store = true;
 
-    bool warm = (seg != 0);
-    size_t pos = warm ? seg_start - WARM : 0;
-    const bool al8 = (reinterpret_cast<uintptr_t>(in) & 7u) == 0; // (pos is even)
-    auto issue = [&](size_t p, int cnt) -> uint2_t {
+    // history of stage 0 after n inputs were consumed: entry by entry (n may be odd at the ragged end of a call)
+    auto hist0 = [&](int n) {
+        short *pl = reinterpret_cast<short *>(p0 + (lane >> 5) * W0STR);
+        const int e = lane & 31;
+        wave_sync();
+        const short v = pl[n + e];
+        wave_sync();
+        pl[e] = v;
+        wave_sync();
+    };
+    // ---- one block at a time with its own loads and every guard: the warm-up of a segment (in front of every store of the
+    // wave), and what the pairs do not cover -- an odd block, a ragged end, an unaligned input: the last segment of a call
+    auto single = [&](size_t pos, int cnt, bool store) {
         const int m = 2 * lane;
         uint2_t v = (uint2_t){0u, 0u};
-        if (m + 1 < cnt && al8) v = SDRHIP_STREAM_LOAD(reinterpret_cast<const uint2_t *>(in + p + m));
-        else {
-            if (m < cnt) v.x = SDRHIP_STREAM_LOAD(in + p + m);
-            if (m + 1 < cnt) v.y = SDRHIP_STREAM_LOAD(in + p + m + 1);
-        }
-        return v;
+#if W_ABL & 64
+        v.x = (unsigned)pos;
+#else
+        if (m < cnt) v.x = SDRHIP_STREAM_LOAD(in + pos + m);
+        if (m + 1 < cnt) v.y = SDRHIP_STREAM_LOAD(in + pos + m + 1);
+#endif
+        p0[W0HIST + lane] = __builtin_amdgcn_perm(v.y, v.x, 0x05040100u);
+        p0[W0STR + W0HIST + lane] = __builtin_amdgcn_perm(v.y, v.x, 0x07060302u);
+        wave_sync();
+        oc.store = store;
+        wdescend<G, 0, false>(lds, lane, 0, cnt, oc);
+        hist0(cnt);
     };
-    int cnt = warm ? WARM : (int)((seg_end - pos) < (size_t)WB ? (seg_end - pos) : (size_t)WB);
-    uint2_t ld = issue(pos, cnt);
-    unsigned *p0 = reinterpret_cast<unsigned *>(lds);
-    while (true) {
-        // de-interleave: packed I pairs and Q pairs (dword `lane` of the block's fresh part)
-        const unsigned pi = __builtin_amdgcn_perm(ld.y, ld.x, 0x05040100u), pq = __builtin_amdgcn_perm(ld.y, ld.x, 0x07060302u);
-        p0[W0HIST + lane] = pi;
-        p0[W0STR + W0HIST + lane] = pq;
-        const size_t next_pos = pos + cnt;
-        const bool more = next_pos < seg_end;
-        int next_cnt = 0;
-        if (more) {
-            next_cnt = (int)((seg_end - next_pos) < (size_t)WB ? (seg_end - next_pos) : (size_t)WB);
-            ld = issue(next_pos, next_cnt); // in flight while this block computes
+
+    size_t pos = seg_start;
+    if (seg != 0) single(seg_start - WARM, WARM, false); // histories of the slice from the 64 inputs in front of it, stores suppressed
+    oc.store = true;
+    for (int p = 0; p < npairs; ++p) {
+        // the pair's 256 samples: lane t holds samples 4t .. 4t+3 -> packed dwords 2t, 2t+1 of both planes
+        uint4_t v;
+        bool got = false;
+#pragma unroll
+        for (int q = 0; q < WPAIRS; ++q)
+            if (!got && p == q) { // (wave-uniform: a scalar branch per candidate)
+                asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                             : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w) : "a"(A[4 * q]), "a"(A[4 * q + 1]), "a"(A[4 * q + 2]), "a"(A[4 * q + 3]));
+                got = true;
+            }
+        const uint2_t pi = (uint2_t){__builtin_amdgcn_perm(v.y, v.x, 0x05040100u), __builtin_amdgcn_perm(v.w, v.z, 0x05040100u)};
+        const uint2_t pq = (uint2_t){__builtin_amdgcn_perm(v.y, v.x, 0x07060302u), __builtin_amdgcn_perm(v.w, v.z, 0x07060302u)};
+        *reinterpret_cast<uint2_t *>(p0 + W0HIST + 2 * lane) = pi;
+        *reinterpret_cast<uint2_t *>(p0 + W0STR + W0HIST + 2 * lane) = pq;
+        wave_sync();
+        wdescend<G, 0, true>(lds, lane, 0, WB, oc);
+        wdescend<G, 0, true>(lds, lane, 1, WB, oc);
+        // history of stage 0: the pair's last 32 samples, straight from the registers of lanes 56 .. 63
+        wave_sync();
+        if (lane >= 56) {
+            *reinterpret_cast<uint2_t *>(p0 + 2 * (lane - 56)) = pi;
+            *reinterpret_cast<uint2_t *>(p0 + W0STR + 2 * (lane - 56)) = pq;
         }
-        oc.store = !warm;
-        wdescend<G, 0>(lds, lane, 0, cnt, oc);
-        // history of stage 0: the last 32 inputs
-        if (cnt == WB) {
-            if (lane >= 48) { p0[lane - 48] = pi; p0[W0STR + lane - 48] = pq; }
-        } else {
-            short *pl = reinterpret_cast<short *>(p0 + (lane >> 5) * W0STR);
-            const int e = lane & 31;
-            const short v = pl[cnt + e];
-            pl[e] = v;
-        }
-        if (!more) break;
-        pos = next_pos;
-        cnt = next_cnt;
-        warm = false;
+        wave_sync();
+        pos += 2 * WB;
+    }
+    while (pos < seg_end) {
+        const int cnt = (int)((seg_end - pos) < (size_t)WB ? (seg_end - pos) : (size_t)WB);
+        single(pos, cnt, true);
+        pos += cnt;
     }
     if (seg == a.nseg - 1) {
         int32_t *stn = a.state_next + (size_t)stream * INT_STATE_WORDS;
+        wave_sync();
         wstate_store<G>(lds, lane, stn);
         for (int i = NS * 2 * INT_HIST + lane; i < INT_STAGES * 2 * INT_HIST; i += WNT) stn[i] = stc[i];
     }

@@ -108,8 +108,9 @@ struct CtxOptions {
     size_t mfma_span = 0;                  // forced span length of the matrix-core decimator (0 = planner's choice)
     size_t mfma_min = (size_t)1 << 22;     // smallest call (samples over all streams, decimate4 / 8) the matrix cores take in auto mode
     int interp_mfma = 0;
-    int interp_wave = 0;                   // interpolate4 .. 64: K5w, the barrier-free wave-private pipeline (interp_wave.h); 0 = K5
+    int interp_wave = 1;                   // interpolate4 .. 64: K5w, the barrier-free wave-private pipeline (interp_wave.h); 0 = K5
     size_t interp_span = 0;
+    int interp_pad = 0;                    // K5w experiments: dynamic LDS per workgroup in bytes (fewer waves per CU)
     int rx_fused = 1;                      // pipelined Rx pipe: encoder in the decimator's launch (0 = separate launches)
     int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)
     int dec_max_rows = 128;                // upper bound of the recovery blocks a received frame can have used (the sender's fecblk)

@@ -51,6 +51,8 @@ while time.time() - t0 < budget:
     ctx.set_option("mfma_span", 1024 * int(rs.choice([1, 1, 2, 3, 5, 16])))
     ctx.set_option("rx_fused", int(rs.randint(0, 2)))
     ctx.set_option("dec_path", str(rs.choice(["syndrome", "syndrome", "dense"])))
+    ctx.set_option("interp_path", str(rs.choice(["wave", "wave", "valu"])))     # K5w (default) / K5
+    ctx.set_option("interp_span", int(rs.choice([0, 0, 128, 256, 640, 2048])))  # segment length in inputs (0 = the planner's)
     if what == "decim":
         S = int(rs.randint(1, 4))
         bias = int(rs.randint(0, 2))

@@ -18,6 +18,6 @@ run b --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_LDS SQ
 # (TA_* / TCP_* counters crash rocprofv3 7.2 on this pool -- signal 6, then a hang until the time limit: left out)
 {
     echo "# command: $CMD"
-    for d in a b; do echo; echo "#### pass $d"; grep -A12 "PMC interp_kernel" $OUT/$d.txt; grep "interp_kernel" $OUT/$d.txt | head -1; done
+    for d in a b; do echo; echo "#### pass $d"; grep -A12 "PMC interp_" $OUT/$d.txt; grep "interp_" $OUT/$d.txt | head -1; done
 } > $OUT/summary.txt
 cat $OUT/summary.txt
