@@ -42,7 +42,7 @@ template <int L> __global__ __launch_bounds__(WNT) void interp_wave_kernel(Inter
 
 template <int L> hipError_t launch_w(const InterpArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((interp_wave_kernel<L>), dim3(a.nseg, a.nstreams), dim3(WNT), a.dyn_lds, stream, a);
+    hipLaunchKernelGGL((interp_wave_kernel<L>), dim3(a.nseg, a.nstreams), dim3(WNT), 0, stream, a);
     return hipGetLastError();
 }
 

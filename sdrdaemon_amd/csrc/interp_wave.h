@@ -18,9 +18,6 @@
 namespace sdrhip {
 namespace {
 
-#ifndef W_ABL
-#define W_ABL 0 // timing experiments (WRONG results): 1 no global stores, 2 no FIR arithmetic in stages >= 1, 4 none in stage 0, 8 stores to one cached slot per wave, 16 non-temporal stores, 64 no input loads
-#endif
 constexpr int WNT = 64;          // one wave
 constexpr int WB = 128;          // inputs per block
 constexpr int WCAP = 256;        // fresh entries a stage buffer (s >= 1) holds
@@ -76,9 +73,6 @@ template <class G, bool FULL> __device__ __forceinline__ void wstage0(int *lds, 
 #pragma unroll
     for (int t = 1; t < 18; ++t) A[t] = __builtin_amdgcn_alignbit(W[t], W[t - 1], 16);
     int acc[4] = {0, 0, 0, 0};
-#if W_ABL & 4
-    acc[0] = (int)(A[1] ^ A[16]); acc[1] = (int)(W[0] ^ W[17]); acc[2] = (int)(A[2] ^ A[17]); acc[3] = (int)(W[3] ^ W[12]);
-#else
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         acc[0] = wdot2(A[16 - e], tap_pair(e), acc[0]);
@@ -86,7 +80,6 @@ template <class G, bool FULL> __device__ __forceinline__ void wstage0(int *lds, 
         acc[2] = wdot2(A[17 - e], tap_pair(e), acc[2]);
         acc[3] = wdot2(W[17 - e], tap_pair(e), acc[3]);
     }
-#endif
     // v[2m] = u[m - 16]: entries 16 .. 19 of the window
     o[0] = (int)(short)(W[8] & 0xffffu); o[2] = (int)W[8] >> 16; o[4] = (int)(short)(W[9] & 0xffffu); o[6] = (int)W[9] >> 16;
     o[1] = acc[0] >> 13; o[3] = acc[1] >> 13; o[5] = acc[2] >> 13; o[7] = acc[3] >> 13;
@@ -111,12 +104,8 @@ template <class G, int S, bool FULL> __device__ __forceinline__ void wstage(int 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         int acc = 0;
-#if W_ABL & 2
-        acc = w[r + 1] ^ w[r + S2];
-#else
 #pragma unroll
         for (int i = 0; i < K; ++i) acc = mad24(w[r + 1 + i] + w[r + S2 - i], tap(O, i), acc);
-#endif
         o[2 * r] = w[r + K]; // u[m - O/4]
         o[2 * r + 1] = acc >> 13;
     }
@@ -144,12 +133,8 @@ template <class G, int S, bool FULL> __device__ __forceinline__ void wstage_last
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             int acc = 0;
-#if W_ABL & 2
-            acc = w[r + 1] ^ w[r + S2];
-#else
 #pragma unroll
             for (int i = 0; i < K; ++i) acc = mad24(w[r + 1 + i] + w[r + S2 - i], 8 * tap(O, i), acc);
-#endif
             ev[comp][r] = w[r + K];
             od[comp][r] = acc; // (acc >> 13) & 0xffff == bits 16..31 of 8 * sum
         }
@@ -163,19 +148,9 @@ template <class G, int S, bool FULL> __device__ __forceinline__ void wstage_last
     size_t idx = oc.out_pos + 2 * (size_t)m0; // chain output index
     if (oc.stuff64) idx = (idx >> 5) * 64 + (idx & 31);
     unsigned *dst = oc.out + idx;
-#if W_ABL & 8
-    dst = oc.out + ((size_t)blockIdx.x * 512 + 2 * (size_t)m0);
-#endif
     if (FULL || m0 + R <= valid) {
-#if W_ABL & 1
-        asm volatile("" ::"v"(pk[0]), "v"(pk[1]), "v"(pk[2]), "v"(pk[3]), "v"(pk[4]), "v"(pk[5]), "v"(pk[6]), "v"(pk[7]), "v"(dst));
-#elif W_ABL & 16
-        __builtin_nontemporal_store((uint4_t){pk[0], pk[1], pk[2], pk[3]}, reinterpret_cast<uint4_t *>(dst));
-        __builtin_nontemporal_store((uint4_t){pk[4], pk[5], pk[6], pk[7]}, reinterpret_cast<uint4_t *>(dst + 4));
-#else
         *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
         *reinterpret_cast<uint4_t *>(dst + 4) = (uint4_t){pk[4], pk[5], pk[6], pk[7]};
-#endif
         if (oc.stuff64) {
             *reinterpret_cast<uint4_t *>(dst + 32) = (uint4_t){0u, 0u, 0u, 0u};
             *reinterpret_cast<uint4_t *>(dst + 36) = (uint4_t){0u, 0u, 0u, 0u};
@@ -280,11 +255,7 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
 #pragma unroll
         for (int p = 0; p < WPAIRS; ++p) { // all of them back to back: ONE cluster of reads per wave
             v[p] = (uint4_t){0u, 0u, 0u, 0u};
-#if W_ABL & 64
-            v[p].x = (unsigned)(p + lane);
-#else
             if (p < npairs) v[p] = SDRHIP_STREAM_LOAD(reinterpret_cast<const uint4_t *>(in + seg_start + (size_t)p * 2 * WB + 4 * lane));
-#endif
         }
 #pragma unroll
         for (int p = 0; p < WPAIRS; ++p)
@@ -317,12 +288,8 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
     auto single = [&](size_t pos, int cnt, bool store) {
         const int m = 2 * lane;
         uint2_t v = (uint2_t){0u, 0u};
-#if W_ABL & 64
-        v.x = (unsigned)pos;
-#else
         if (m < cnt) v.x = SDRHIP_STREAM_LOAD(in + pos + m);
         if (m + 1 < cnt) v.y = SDRHIP_STREAM_LOAD(in + pos + m + 1);
-#endif
         p0[W0HIST + lane] = __builtin_amdgcn_perm(v.y, v.x, 0x05040100u);
         p0[W0STR + W0HIST + lane] = __builtin_amdgcn_perm(v.y, v.x, 0x07060302u);
         wave_sync();

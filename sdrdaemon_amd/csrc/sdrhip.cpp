@@ -198,7 +198,6 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
     } else if (k == "mfma_span" && isnum) c->opt.mfma_span = (size_t)num;
     else if (k == "mfma_min" && isnum) c->opt.mfma_min = (size_t)num;
     else if (k == "interp_span" && isnum) c->opt.interp_span = (size_t)num;
-    else if (k == "interp_pad" && isnum && num <= 65536) c->opt.interp_pad = (int)num;
     else if (k == "rx_fused" && isnum) c->opt.rx_fused = (int)num;
     else if (k == "dec_path") {
         if (v == "syndrome") c->opt.dec_syndrome = 1;

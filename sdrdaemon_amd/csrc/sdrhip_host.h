@@ -110,7 +110,6 @@ struct CtxOptions {
     int interp_mfma = 0;
     int interp_wave = 1;                   // interpolate4 .. 64: K5w, the barrier-free wave-private pipeline (interp_wave.h); 0 = K5
     size_t interp_span = 0;
-    int interp_pad = 0;                    // K5w experiments: dynamic LDS per workgroup in bytes (fewer waves per CU)
     int rx_fused = 1;                      // pipelined Rx pipe: encoder in the decimator's launch (0 = separate launches)
     int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)
     int dec_max_rows = 128;                // upper bound of the recovery blocks a received frame can have used (the sender's fecblk)

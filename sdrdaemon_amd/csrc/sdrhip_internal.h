@@ -172,7 +172,6 @@ struct InterpArgs {
     int32_t *state_next;
     int nstreams;
     int nsub_per_seg, nseg;
-    int dyn_lds;                  // K5w, experiments: bytes of dynamic LDS per workgroup (caps the waves per CU)
     // matrix-core path (interp_mfma.hip): VALU segment 0 and segments >= mf_tail_seg, spans in between
     size_t mf_head, mf_span;      // inputs
     int mf_wps, mf_tail_seg, mf_npieces;

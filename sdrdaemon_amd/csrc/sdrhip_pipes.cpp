@@ -82,7 +82,6 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
     if (c->opt.interp_mfma) use_mfma = plan_interpolate_mfma(log2interp, n_in, p->nstreams, c->opt.interp_span, &a);
 #endif
     const bool use_wave = !use_mfma && c->opt.interp_wave && log2interp >= 2;
-    a.dyn_lds = use_wave ? c->opt.interp_pad : 0;
     if (use_wave) plan_interpolate_wave(log2interp, n_in, p->nstreams, c->n_cu, c->opt.interp_span, &a.nsub_per_seg, &a.nseg);
     else if (!use_mfma) plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
     a.mf_dump = c->decim_dump;

@@ -47,7 +47,6 @@ for L in LS if ONLY is None else (int(ONLY[2]),):
     for path, span in (PATHS if ONLY is None else ((ONLY[0], int(ONLY[1])),)):
         ctx.set_option("interp_path", path)
         ctx.set_option("interp_span", span)
-        ctx.set_option("interp_pad", int(os.environ.get("PAD", "0")))
         d = sd.Interpolators(ctx, S)
         if os.environ.get("PRECOPY"):
             # the input as a kernel in front of the interpolator leaves it (the Tx pipe's decoder writes the payload right before):
