@@ -35,6 +35,7 @@ extern "C" {
 #define SDRHIP_EDEVICE (-3)  /* HIP runtime error (no GPU, launch failure ...) */
 #define SDRHIP_EALIGN (-4)   /* device pointer / stride not 16-byte aligned */
 #define SDRHIP_EDECODE (-5)  /* cm256 decode: duplicate original index / singular system */
+#define SDRHIP_EBUSY (-6)    /* asynchronous entry: nothing to collect yet / every batch of the ring is in flight */
 
 #define SDRHIP_MEM_HOST 0
 #define SDRHIP_MEM_DEVICE 1
@@ -261,6 +262,25 @@ int sdrhip_rx_last_plan(const sdrhip_rx *rx, sdrhip_decim_plan *out);
  * base + s * stream_stride_bytes (device memory, frame after frame).  The view stays valid until
  * the next sdrhip_rx_process / sdrhip_rx_destroy on this handle. */
 int sdrhip_rx_frames_view(const sdrhip_rx *rx, const uint8_t **base, size_t *stream_stride_bytes, size_t *n_frames);
+
+/* Asynchronous host-pointer entry.  The reference's Rx chain is asynchronous end to end (source thread -> source_buffer ->
+ * Downsampler::process -> output_buffer -> writer -> transmit thread, sdrdaemonrx.cpp:555-663): the frames of a block leave the
+ * process long after it was pulled.  sdrhip_rx_submit takes one block of host samples per stream like sdrhip_rx_process
+ * (SDRHIP_MEM_HOST) and returns at once: the block is appended to a pinned staging buffer -- or used IN PLACE when it lies in
+ * sdrhip_host_alloc memory, which the caller then leaves untouched until the batch is collected -- and every `blocks` blocks go
+ * out as one upload + launch + download on the context's stream.  sdrhip_rx_collect returns the finished frames of the OLDEST
+ * batch ((128 + nb_fec) super blocks per frame, stream s at frames_out + s * frame_stride_bytes; sdrhip_rx_max_frames() of the
+ * batch's samples bounds them): wait = 0 returns SDRHIP_EBUSY while that batch is still in flight or being filled, wait = 1
+ * blocks (a partly filled batch is launched as it is: end of stream).  At most `depth` batches are in flight; sdrhip_rx_submit
+ * returns SDRHIP_EBUSY when the ring is full.  Defaults (no sdrhip_rx_set_async call): depth 4, one block per batch.  tv_sec /
+ * tv_usec of a batch = those of its first block (frames are stamped by the sample clock from there, see sdrhip_rx_process).
+ * Do not mix sdrhip_rx_process calls into a submit / collect sequence while batches are in flight. */
+int sdrhip_rx_set_async(sdrhip_rx *rx, int depth, int blocks);
+int sdrhip_rx_submit(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in, size_t in_stride, uint32_t tv_sec, uint32_t tv_usec);
+int sdrhip_rx_collect(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames, int wait);
+/* Pinned host memory for the source side (the buffers a DeviceSource pushes): blocks submitted from it skip the staging copy. */
+void *sdrhip_host_alloc(sdrhip_ctx *ctx, size_t bytes);
+void sdrhip_host_free(sdrhip_ctx *ctx, void *p);
 
 /* ------------------------------------------------------------ fused Tx pipe -- */
 /* Bank of Tx chains: SDRdaemonFECBuffer decode (SDRdaemonFECBuffer.cpp:143-213) ->

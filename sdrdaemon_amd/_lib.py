@@ -24,7 +24,7 @@ HB_EO1, HB_DB = 0, 1
 UDPSIZE, NB_ORIGINAL, BLOCK_BYTES, SAMPLES_PER_BLOCK, SAMPLES_PER_FRAME = 512, 128, 508, 127, 16129
 
 EXPORTS = [
-    "sdrhip_last_error", "sdrhip_device_count", "sdrhip_ctx_create", "sdrhip_ctx_destroy", "sdrhip_ctx_synchronize", "sdrhip_ctx_set_option", "sdrhip_ctx_get_counter", "sdrhip_decimators_last_plan", "sdrhip_rx_last_plan", "sdrhip_rx_set_pipelined", "sdrhip_rx_flush",
+    "sdrhip_last_error", "sdrhip_device_count", "sdrhip_ctx_create", "sdrhip_ctx_destroy", "sdrhip_ctx_synchronize", "sdrhip_ctx_set_option", "sdrhip_ctx_get_counter", "sdrhip_decimators_last_plan", "sdrhip_rx_last_plan", "sdrhip_rx_set_pipelined", "sdrhip_rx_flush", "sdrhip_rx_set_async", "sdrhip_rx_submit", "sdrhip_rx_collect", "sdrhip_host_alloc", "sdrhip_host_free",
     "sdrhip_ctx_timing_begin", "sdrhip_ctx_timing_end", "sdrhip_ctx_kernel_timing", "sdrhip_ctx_kernel_timing_read", "sdrhip_decimators_create", "sdrhip_decimators_destroy",
     "sdrhip_decimators_reset", "sdrhip_decimate", "sdrhip_interpolators_create", "sdrhip_interpolators_destroy",
     "sdrhip_interpolators_reset", "sdrhip_interpolate", "sdrhip_cm256_encode", "sdrhip_cm256_decode",
@@ -100,6 +100,13 @@ def load():
     lib.sdrhip_rx_frames_view.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
     lib.sdrhip_rx_set_pipelined.argtypes = [vp, i]
     lib.sdrhip_rx_flush.argtypes = [vp, vp, sz, C.POINTER(sz), i]
+    lib.sdrhip_rx_set_async.argtypes = [vp, i, i]
+    lib.sdrhip_rx_submit.argtypes = [vp, vp, sz, sz, C.c_uint32, C.c_uint32]
+    lib.sdrhip_rx_collect.argtypes = [vp, vp, sz, C.POINTER(sz), i]
+    lib.sdrhip_host_alloc.argtypes = [vp, sz]
+    lib.sdrhip_host_alloc.restype = vp
+    lib.sdrhip_host_free.argtypes = [vp, vp]
+    lib.sdrhip_host_free.restype = None
     lib.sdrhip_rx_max_frames.argtypes = [vp, sz]
     lib.sdrhip_rx_max_frames.restype = sz
     lib.sdrhip_tx_create.argtypes = [vp, i, i, C.POINTER(vp)]

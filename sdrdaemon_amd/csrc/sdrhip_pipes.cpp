@@ -167,6 +167,23 @@ struct sdrhip_rx {
         size_t slot0 = 0;           // window position inside `work` (overlap check of the sliding window), SIZE_MAX = other area
     } late;
     DevBuf old_work;          // the previous frame area after a re-allocation, kept while `late` points into it
+    // ---- asynchronous host-pointer entry (sdrhip_rx_submit / sdrhip_rx_collect): a ring of batches
+    struct Batch {
+        PinnedBuf in;             // the submitted blocks, appended: [block][stream][n] (unless the caller's memory is pinned by us)
+        DevBuf din;               // [stream][dstride] on the device
+        PinnedBuf out;            // the batch's finished frames [stream][frames][128 + R][512]
+        hipEvent_t done = nullptr;
+        std::vector<std::pair<const int16_t *, size_t> > blocks; // source of each block (host address, samples per stream) and
+        std::vector<size_t> strides;                             // its stream stride in samples
+        size_t n_in = 0;          // samples per stream so far
+        size_t in_cap = 0;        // row length of `in` in samples: staged blocks lie stream-major, [stream][in_cap], at their batch offset
+        uint32_t tv_sec = 0, tv_usec = 0;
+        size_t frames = 0, frame_bytes = 0;
+        int state = 0;            // 0 free, 1 filling, 2 in flight
+    };
+    std::vector<Batch> abatch;
+    int a_blocks = 1;             // blocks per launch
+    size_t a_head = 0, a_tail = 0; // next batch to collect / batch being filled
 };
 
 static int rx_check_config(const sdrhip_rx_config *cfg);
@@ -260,6 +277,10 @@ extern "C" void sdrhip_rx_destroy(sdrhip_rx *rx)
     rx->lin[0].release();
     rx->lin[1].release();
     rx->flist.release();
+    for (auto &b : rx->abatch) {
+        if (b.done) { (void)hipEventSynchronize(b.done); (void)hipEventDestroy(b.done); }
+        b.in.release(); b.din.release(); b.out.release();
+    }
     delete rx;
 }
 
@@ -560,6 +581,188 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     rx->frame_open = rest > 0;
     rx->frame_count = (uint16_t)(rx->frame_count + done);
     if (mem == SDRHIP_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDRHIP_OK;
+}
+
+// --------------------------------------------------------------------------- asynchronous host-pointer Rx entry
+// sdrdaemonrx's chain is asynchronous end to end (source thread -> source_buffer -> main loop -> output_buffer -> writer ->
+// transmit thread, sdrdaemonrx.cpp:555-663): a block's frames leave the process long after Downsampler::process returned.
+// sdrhip_rx_process on host pointers is one synchronous launch per block (38 us for a 65 536-sample TestSource block, of which
+// the GPU works ~10); submit / collect give the host-pointer path the same asynchrony: blocks are appended to a pinned
+// staging buffer (or taken in place from sdrhip_host_alloc memory), every `blocks` of them go out as ONE upload + launch +
+// download on the context's stream, and the frames are collected later, batch by batch, in order.
+namespace {
+// memory handed out by sdrhip_host_alloc: pinned, usable in place
+struct HostRange { const char *p; size_t n; };
+std::mutex g_host_mtx;
+std::vector<HostRange> g_host_ranges;
+bool host_is_pinned(const void *p, size_t n)
+{
+    std::lock_guard<std::mutex> g(g_host_mtx);
+    const char *c = static_cast<const char *>(p);
+    for (const HostRange &r : g_host_ranges)
+        if (c >= r.p && c + n <= r.p + r.n) return true;
+    return false;
+}
+int rx_launch_batch(sdrhip_rx *rx, sdrhip_rx::Batch &b)
+{
+    sdrhip_ctx *c = rx->ctx;
+    const int S = rx->nstreams;
+    const size_t dstride = (b.n_in + 3) & ~(size_t)3;
+    int rc;
+    if ((rc = b.din.reserve((size_t)S * dstride * 4 + 16))) return rc;
+    // uploads: runs of blocks that are adjacent in host memory go out as ONE 2-D copy (a run of staged blocks -- stream-major in
+    // the pinned arena -- or of in-place blocks cut from one buffer)
+    size_t off = 0;
+    for (size_t i = 0; i < b.blocks.size();) {
+        const int16_t *src = b.blocks[i].first;
+        size_t sstride = b.strides[i], n = b.blocks[i].second, j = i + 1;
+        if (!src) { // staged: [stream][in_cap] at sample offset `off` of every row (all staged blocks of a batch are one run)
+            src = b.in.as<int16_t>() + off * 2;
+            sstride = b.in_cap;
+            while (j < b.blocks.size() && !b.blocks[j].first) n += b.blocks[j++].second;
+        } else {
+            while (j < b.blocks.size() && b.blocks[j].first == src + n * 2 && b.strides[j] == sstride) n += b.blocks[j++].second;
+        }
+        if (S == 1) HIP_TRY(hipMemcpyAsync(b.din.as<char>() + off * 4, src, n * 4, hipMemcpyHostToDevice, c->stream)); // (no pitch limits)
+        else HIP_TRY(hipMemcpy2DAsync(b.din.as<char>() + off * 4, dstride * 4, src, sstride * 4, n * 4, S, hipMemcpyHostToDevice, c->stream));
+        off += n;
+        i = j;
+    }
+    b.in.mark(c->stream);
+    size_t nf = 0;
+    rc = sdrhip_rx_process(rx, b.din.as<int16_t>(), b.n_in, dstride, b.tv_sec, b.tv_usec, nullptr, 0, &nf, SDRHIP_MEM_DEVICE);
+    if (rc) return rc;
+    b.frames = nf;
+    b.frame_bytes = (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
+    if (nf) {
+        if ((rc = b.out.reserve((size_t)S * nf * b.frame_bytes))) return rc;
+        if (S == 1) HIP_TRY(hipMemcpyAsync(b.out.p, rx->view_base, nf * b.frame_bytes, hipMemcpyDeviceToHost, c->stream));
+        else HIP_TRY(hipMemcpy2DAsync(b.out.p, nf * b.frame_bytes, rx->view_base, rx->view_stride, nf * b.frame_bytes, S, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (!b.done) HIP_TRY(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b.done, c->stream));
+    b.state = 2;
+    return SDRHIP_OK;
+}
+} // namespace
+
+extern "C" void *sdrhip_host_alloc(sdrhip_ctx *c, size_t bytes)
+{
+    if (!c || bytes == 0) return nullptr;
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)fail(SDRHIP_ENOMEM, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    std::lock_guard<std::mutex> g(g_host_mtx);
+    g_host_ranges.push_back(HostRange{static_cast<const char *>(p), bytes});
+    return p;
+}
+
+extern "C" void sdrhip_host_free(sdrhip_ctx *c, void *p)
+{
+    if (!p) return;
+    (void)c;
+    {
+        std::lock_guard<std::mutex> g(g_host_mtx);
+        for (size_t i = 0; i < g_host_ranges.size(); ++i)
+            if (g_host_ranges[i].p == p) { g_host_ranges.erase(g_host_ranges.begin() + (long)i); break; }
+    }
+    (void)hipHostFree(p);
+}
+
+extern "C" int sdrhip_rx_set_async(sdrhip_rx *rx, int depth, int blocks)
+{
+    if (!rx) return fail(SDRHIP_EINVAL, "rx is NULL");
+    sdrhip::CtxLock lock_(rx->ctx);
+    if (depth < 1 || depth > 64 || blocks < 1 || blocks > 1024) return fail(SDRHIP_EINVAL, "rx_set_async: depth 1..64, blocks 1..1024");
+    for (auto &b : rx->abatch)
+        if (b.state != 0) return fail(SDRHIP_EINVAL, "rx_set_async: batches are in flight: collect them first");
+    for (auto &b : rx->abatch) { if (b.done) (void)hipEventDestroy(b.done); b.in.release(); b.din.release(); b.out.release(); }
+    rx->abatch.assign((size_t)depth, sdrhip_rx::Batch());
+    rx->a_blocks = blocks; rx->a_head = rx->a_tail = 0;
+    return SDRHIP_OK;
+}
+
+extern "C" int sdrhip_rx_submit(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in, size_t in_stride, uint32_t tv_sec, uint32_t tv_usec)
+{
+    if (!rx) return fail(SDRHIP_EINVAL, "rx is NULL");
+    sdrhip::CtxLock lock_(rx->ctx);
+    if (n_in == 0) return SDRHIP_OK;
+    if (!iq_in) return fail(SDRHIP_EINVAL, "rx_submit: NULL input");
+    if (rx->abatch.empty()) { rx->abatch.assign(4, sdrhip_rx::Batch()); rx->a_blocks = 1; }
+    HIP_TRY(hipSetDevice(rx->ctx->device));
+    const int S = rx->nstreams;
+    if (S == 1) in_stride = n_in;
+    sdrhip_rx::Batch &b = rx->abatch[rx->a_tail % rx->abatch.size()];
+    if (b.state == 2) return fail(SDRHIP_EBUSY, "rx_submit: every batch of the ring is in flight: sdrhip_rx_collect first");
+    if (b.state == 0) {
+        b.blocks.clear(); b.strides.clear(); b.n_in = 0; b.tv_sec = tv_sec; b.tv_usec = tv_usec; b.state = 1;
+    }
+    if (host_is_pinned(iq_in, ((size_t)(S - 1) * in_stride + n_in) * 4)) {
+        b.blocks.push_back(std::make_pair(iq_in, n_in)); // in place: the caller keeps it untouched until the batch is collected
+        b.strides.push_back(in_stride);
+    } else {
+        // staged: row s of the pinned arena holds stream s, the block at the batch's current sample offset
+        const size_t need = b.n_in + n_in;
+        if (b.n_in == 0) {
+            b.in_cap = (size_t)rx->a_blocks * n_in > need ? (size_t)rx->a_blocks * n_in : need;
+            int rc = b.in.reserve((size_t)S * b.in_cap * 4); // (waits for the upload of the batch that used this buffer last)
+            if (rc) return rc;
+        } else if (need > b.in_cap) { // blocks longer than the first one: re-lay the rows out in a bigger arena
+            PinnedBuf bigger;
+            const size_t ncap = 2 * need;
+            int rc = bigger.reserve((size_t)S * ncap * 4);
+            if (rc) return rc;
+            for (int s = 0; s < S; ++s) memcpy(bigger.as<char>() + (size_t)s * ncap * 4, b.in.as<char>() + (size_t)s * b.in_cap * 4, b.n_in * 4);
+            b.in.release();
+            b.in = bigger;
+            b.in_cap = ncap;
+        }
+        for (int s = 0; s < S; ++s) memcpy(b.in.as<char>() + ((size_t)s * b.in_cap + b.n_in) * 4, iq_in + (size_t)s * in_stride * 2, n_in * 4);
+        b.blocks.push_back(std::make_pair((const int16_t *)nullptr, n_in));
+        b.strides.push_back(n_in);
+    }
+    b.n_in += n_in;
+    if ((int)b.blocks.size() >= rx->a_blocks) {
+        int rc = rx_launch_batch(rx, b);
+        if (rc) return rc;
+        ++rx->a_tail;
+    }
+    return SDRHIP_OK;
+}
+
+extern "C" int sdrhip_rx_collect(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames, int wait)
+{
+    if (!rx || !n_frames) return fail(SDRHIP_EINVAL, "rx_collect: NULL argument");
+    sdrhip::CtxLock lock_(rx->ctx);
+    *n_frames = 0;
+    if (rx->abatch.empty()) return SDRHIP_OK;
+    HIP_TRY(hipSetDevice(rx->ctx->device));
+    sdrhip_rx::Batch &b = rx->abatch[rx->a_head % rx->abatch.size()];
+    if (b.state == 0) return SDRHIP_OK; // nothing submitted
+    if (b.state == 1) {
+        if (!wait) return fail(SDRHIP_EBUSY, "rx_collect: the oldest batch is still being filled (wait = 1 launches it as it is)");
+        int rc = rx_launch_batch(rx, b); // a partly filled batch goes out as it is (end of stream)
+        if (rc) return rc;
+        ++rx->a_tail;
+    }
+    if (!wait) {
+        const hipError_t q = hipEventQuery(b.done);
+        if (q == hipErrorNotReady) return fail(SDRHIP_EBUSY, "rx_collect: the oldest batch is still in flight");
+        if (q != hipSuccess) return fail(SDRHIP_EDEVICE, "hipEventQuery: %s", hipGetErrorString(q));
+    } else {
+        HIP_TRY(hipEventSynchronize(b.done));
+    }
+    const int S = rx->nstreams;
+    if (b.frames) {
+        if (!frames_out) return fail(SDRHIP_EINVAL, "rx_collect: NULL frames_out");
+        const size_t row = b.frames * b.frame_bytes;
+        if (S > 1 && frame_stride_bytes < row) return fail(SDRHIP_EINVAL, "rx_collect: frame stride too small");
+        for (int s = 0; s < S; ++s) memcpy(frames_out + (size_t)s * (S > 1 ? frame_stride_bytes : row), b.out.as<char>() + (size_t)s * row, row);
+    }
+    *n_frames = b.frames;
+    b.state = 0;
+    ++rx->a_head;
     return SDRHIP_OK;
 }
 

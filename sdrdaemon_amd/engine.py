@@ -59,6 +59,24 @@ class Context:
         interp_span, rx_fused; the defaults were read from the SDRHIP_* environment when the context was created"""
         check(self.lib.sdrhip_ctx_set_option(self.h, str(key).encode(), str(value).encode()))
 
+    def host_alloc(self, shape, dtype=np.int16):
+        """numpy array on pinned host memory of the library (sdrhip_host_alloc): blocks submitted from it are uploaded in
+        place.  Keep the Context alive while the array is in use; free with host_free(array)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.sdrhip_host_alloc(self.h, n)
+        if not p:
+            raise MemoryError("sdrhip_host_alloc(%d) failed" % n)
+        buf = (C.c_char * n).from_address(p)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._host_allocs = getattr(self, "_host_allocs", {})
+        self._host_allocs[a.ctypes.data] = p
+        return a
+
+    def host_free(self, a):
+        p = getattr(self, "_host_allocs", {}).pop(a.ctypes.data, None)
+        if p:
+            self.lib.sdrhip_host_free(self.h, C.c_void_p(p))
+
     def counter(self, key):
         """device-side event counters (sdrhip_ctx_get_counter; synchronises): "dec_rows_exceeded" = frames the batched decoder
         left unrepaired because they carried more recovery blocks than the dec_max_rows option promises"""
@@ -528,6 +546,38 @@ class RxPipe:
 
     def max_frames(self, n_in):
         return self.ctx.lib.sdrhip_rx_max_frames(self.h, n_in)
+
+    # ---- asynchronous host-pointer entry (sdrhip_rx_submit / sdrhip_rx_collect)
+    def set_async(self, depth=4, blocks=1):
+        """ring of `depth` batches, `blocks` submitted blocks per upload + launch + download"""
+        check(self.ctx.lib.sdrhip_rx_set_async(self.h, depth, blocks))
+        self._async_cap = 0
+
+    def submit(self, iq, tv_sec=0, tv_usec=0):
+        """one block of host samples per stream (numpy; memory from Context.host_alloc is used in place); returns at once.
+        Raises SdrHipError(code SDRHIP_EBUSY = -6) when every batch of the ring is in flight."""
+        if _is_torch(iq):
+            raise TypeError("submit takes host memory")
+        a = np.asarray(iq)
+        if a.ndim == 3 and a.dtype == np.int16 and a.shape[0] == self.nstreams and a.shape[2] == 2 and a.strides[2] == 2 and a.strides[1] == 4 and a.strides[0] % 4 == 0:
+            x = a  # rows of a bigger array (e.g. a pinned buffer): passed in place with their stride
+        else:
+            x, _, _ = _bank_view(iq, self.nstreams)
+        self._async_cap = getattr(self, "_async_cap", 0) + x.shape[1]
+        check(self.ctx.lib.sdrhip_rx_submit(self.h, _ptr(x), x.shape[1], _stride_samples(x), tv_sec, tv_usec))
+
+    def collect(self, wait=True, max_frames=None):
+        """-> the finished frames of the oldest batch (S, n, 128 + nb_fec, 512), or None while it is still in flight / being
+        filled (wait = False)"""
+        cap = max_frames if max_frames is not None else max(getattr(self, "_async_cap", 0) // (SAMPLES_PER_FRAME << self.cfg.log2decim) + 2, 1)
+        fb = (NB_ORIGINAL + self.nb_fec) * UDPSIZE
+        out = np.empty((self.nstreams, cap, NB_ORIGINAL + self.nb_fec, UDPSIZE), np.uint8)
+        nf = C.c_size_t(0)
+        rc = self.ctx.lib.sdrhip_rx_collect(self.h, _ptr(out), cap * fb, C.byref(nf), 1 if wait else 0)
+        if rc == -6 and not wait:
+            return None
+        check(rc)
+        return out[:, :nf.value]
 
     def process(self, iq, tv_sec=0, tv_usec=0, out=None):
         """-> frames (S, n_frames, 128 + nb_fec, 512) uint8 (squeezed for one stream)"""

@@ -395,3 +395,59 @@ def test_last_plan_reports_no_cascade_after_a_filterless_call(ctx):
     d.decimate(4, 2, 16, x)
     d.decimate(4, 2, 16, x[:3])
     assert d.last_plan()["path"] is None
+
+
+@pytest.mark.parametrize("blocks,pinned,pipelined", [(1, False, False), (3, False, False), (4, True, False), (2, False, True), (5, True, True)])
+def test_rx_submit_collect_equals_the_synchronous_pipe(ctx, oracle, blocks, pinned, pipelined):
+    """sdrhip_rx_submit / sdrhip_rx_collect (asynchronous host-pointer entry, VERDICT r3 missing #3): 13 TestSource-sized blocks of
+    two streams, `blocks` per batch, staged or in place (sdrhip_host_alloc memory); the collected frames, batch by batch, are the
+    frames of the synchronous pipe fed with the same batches -- and the oracle chain's."""
+    import sdrdaemon_amd as sd
+
+    S, nb, n = 2, 13, 65536
+    xs = np.stack([signals.noise(nb * n, 700 + s) for s in range(S)])
+    if pinned:
+        buf = ctx.host_alloc((S, nb * n, 2))
+        buf[:] = xs
+        src = buf
+    else:
+        src = xs
+    a = sd.RxPipe(ctx, S, log2decim=4, nb_fec=32, pipelined=pipelined)
+    p = sd.RxPipe(ctx, S, log2decim=4, nb_fec=32, pipelined=pipelined)
+    p.set_async(depth=3, blocks=blocks)
+    exp, got, inflight = [], [], 0
+    for b in range(nb):
+        p.submit(src[:, b * n:(b + 1) * n], 50 + b, 7 * b)
+        if (b + 1) % blocks == 0:
+            inflight += 1
+            lo = (b + 1 - blocks) * n
+            exp.append(a.process(xs[:, lo:(b + 1) * n], 50 + b + 1 - blocks, 7 * (b + 1 - blocks)))
+        if inflight == 3:  # the ring is full: the next submit that starts a batch must say so
+            with pytest.raises(sd.SdrHipError) as e:
+                p.submit(src[:, :n], 0, 0)
+            assert e.value.code == -6
+            got.append(p.collect(wait=True))
+            inflight -= 1
+    while inflight:
+        got.append(p.collect(wait=True))
+        inflight -= 1
+    rest = nb % blocks
+    if rest:  # a partly filled batch: wait = 0 refuses, wait = 1 launches it as it is
+        assert p.collect(wait=False) is None
+        got.append(p.collect(wait=True))
+        exp.append(a.process(xs[:, (nb - rest) * n:], 50 + nb - rest, 7 * (nb - rest)))
+    assert p.collect(wait=True).shape[1] == 0  # nothing left
+    if pipelined:
+        got.append(p.flush()); exp.append(a.flush())
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert g.shape == e.shape and np.array_equal(g, e)
+    got = np.concatenate(got, axis=1)
+    assert got.shape[1] == (nb * n >> 4) // 16129
+    for s in range(S):
+        y, _ = oracle.decimators(0).decimate(4, 2, 16, xs[s])
+        for f in range(got.shape[1]):
+            assert np.array_equal(got[s, f, 1:128, 4:].reshape(-1).view(np.int16).reshape(-1, 2), y[f * 16129:(f + 1) * 16129]), (s, f)
+            assert np.array_equal(got[s, f, 128:], oracle.frame_encode(got[s, f, :128], 32)), (s, f)
+    if pinned:
+        ctx.host_free(src)

@@ -49,3 +49,43 @@ for n in (65536, 262144, 1 << 20, 1 << 22, 1 << 24):
             rx.process(x, 1, 2)
         th = (time.perf_counter() - t0) / K * 1e6
         print("rx pipe, %8d samples per call, host pointers%s: %8.1f us per call = %7.1f M samples/s" % (n, " (pipelined)" if pipelined else "", th, n / th), flush=True)
+
+# the asynchronous entry (sdrhip_rx_submit / sdrhip_rx_collect): 65 536-sample blocks, k per upload + launch + download, the
+# collector one batch behind the submitter; staged (pageable source -> memcpy into pinned) and in place (sdrhip_host_alloc)
+n = 65536
+for pinned in (False, True):
+    for blocks in (1, 4, 8, 16, 32):
+        nb = 16 * blocks
+        if pinned:
+            src = ctx.host_alloc((1, nb * n, 2))
+            src[:] = np.random.default_rng(3).integers(-32768, 32768, (1, nb * n, 2), dtype=np.int16)
+        else:
+            src = np.random.default_rng(3).integers(-32768, 32768, (1, nb * n, 2), dtype=np.int16)
+        rx = sd.RxPipe(ctx, 1, log2decim=4, nb_fec=32)
+        rx.set_async(depth=4, blocks=blocks)
+
+        blks = [src[:, b * n:(b + 1) * n] for b in range(nb)]
+
+        def run(rounds):
+            inflight = 0
+            for r in range(rounds):
+                for b in range(nb):
+                    rx.submit(blks[b], 1, 2)
+                    if (b + 1) % blocks == 0:
+                        inflight += 1
+                        if inflight == 3:
+                            rx.collect(wait=True, max_frames=blocks * 65536 // (16129 * 16) + 2)
+                            inflight -= 1
+            while inflight:
+                rx.collect(wait=True, max_frames=blocks * 65536 // (16129 * 16) + 2)
+                inflight -= 1
+
+        run(1)
+        R = max(1, 64 // blocks)
+        t0 = time.perf_counter()
+        run(R)
+        dt = time.perf_counter() - t0
+        print("rx submit / collect, 65536-sample blocks, %2d per batch, %s: %7.1f us per block = %7.1f M samples/s" %
+              (blocks, "in place (pinned source)" if pinned else "staged (pageable source) ", dt / (R * nb) * 1e6, R * nb * n / dt / 1e6), flush=True)
+        if pinned:
+            ctx.host_free(src)
