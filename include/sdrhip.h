@@ -78,7 +78,11 @@ int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
  * blocks a received frame can carry (the sender's fecblk, known from the meta block); <= 32 spares the batched decoder the
  * launches of its fallback kernel.  The promise is checked on the device: a frame that carries MORE recovery blocks than
  * dec_max_rows is left as received (like an undecodable frame: missing originals read zero) and counted, see
- * sdrhip_ctx_get_counter("dec_rows_exceeded"). */
+ * sdrhip_ctx_get_counter("dec_rows_exceeded").  One knob selects behaviour: "dec_strict" = 0 | 1 (default 0).  The reference copies
+ * back only the descriptors [128 - recoveryCount, 128) after cm256_decode (SDRdaemonFECBuffer.cpp:204-211: it relies on the
+ * recovery blocks arriving last), so a block restored into a recovery block that arrived BEFORE some original is never copied
+ * and stays a hole; by default the batched decoder delivers every restored block (a superset), with dec_strict = 1 exactly the
+ * reference's frames, holes included. */
 int sdrhip_ctx_set_option(sdrhip_ctx *ctx, const char *key, const char *value);
 /* Event counters of the context, kept on the device (reading one synchronises the context's stream).  Keys:
  * "dec_rows_exceeded" = frames, since the context was created, that the batched decoder (sdrhip_fec_decode_frames,

@@ -38,28 +38,41 @@ constexpr int KLEAVES = 81;                                                     
 __host__ __device__ constexpr int pow3(int n) { return n <= 1 ? 1 : 3 * pow3(n / 2); }    // leaves of an n-point node
 __host__ __device__ constexpr int sbase(int n) { return KN + (KN - n); }                  // scratch of the level of size n
 
+// the multiplier tables of the leaves travel through two register sets: while leaf L is multiplied, the tables of leaf L + 1 are
+// already on their way from LDS (round 4: with load + wait inside every leaf a wave spent most of its time in s_waitcnt --
+// SQ_WAIT_ANY 57 % of the decoder's wave cycles, `tools/experiments_r04/exp14.sh` -- four waves per SIMD do not cover 162
+// dependent LDS round trips per walk)
+struct LeafRegs {
+    uint4_t ta[2], tb[2];
+    unsigned tca[2], tcb[2];
+};
+template <int LEAF, int P> __device__ __forceinline__ void leaf_issue(LeafRegs &R, unsigned la16, unsigned la4, unsigned lb16, unsigned lb4)
+{
+    asm volatile("ds_read_b128 %0, %4 offset:%c8\n\tds_read_b32 %1, %5 offset:%c9\n\t"
+                 "ds_read_b128 %2, %6 offset:%c8\n\tds_read_b32 %3, %7 offset:%c9"
+                 : "=&v"(R.ta[P]), "=&v"(R.tca[P]), "=&v"(R.tb[P]), "=&v"(R.tcb[P])
+                 : "v"(la16), "v"(la4), "v"(lb16), "v"(lb4), "i"(LEAF * 16), "i"(LEAF * 4)
+                 : "memory");
+}
+
 // ya[YO .. YO+N) ^= ga (*) v[ZO .. ZO+N) and yb[..] ^= gb (*) v[..] in one walk of the Karatsuba tree: the two
 // kernel blocks (the two 16-row tiles of a row pair) see the same z sums, so the tree's XORs on the z side
 // and the three selector words of every leaf are formed once and used twice.  la16 / la4, lb16 / lb4 = LDS
-// byte addresses of the leaf tables of the two blocks.
+// byte addresses of the leaf tables of the two blocks.  The caller issues leaf 0 (leaf_issue<0, 0>) in front of the walk.
 template <int N, int ZO, int YO, int LEAF0>
 __device__ __forceinline__ void acc_conv2(unsigned (&v)[2 * KN - 1], unsigned (&ya)[KN], unsigned (&yb)[KN], unsigned la16, unsigned la4,
-                                          unsigned lb16, unsigned lb4)
+                                          unsigned lb16, unsigned lb4, LeafRegs &R)
 {
     if constexpr (N == 1) {
-        // The 81 table loads of a block have immediate addresses; left to the compiler they are all
-        // hoisted to the top (hundreds of VGPRs of tables) and spilled.  An asm statement that loads one
-        // leaf's tables and waits for them keeps them in program order; the other waves of the SIMD cover
-        // the LDS latency.
-        uint4_t ta, tb;
-        unsigned tca, tcb;
+        // The 81 table loads of a block have immediate addresses; left to the compiler they are all hoisted to the top
+        // (hundreds of VGPRs of tables) and spilled.  asm statements keep them in program order, one leaf ahead.
+        constexpr int P = LEAF0 & 1;
         unsigned z = v[ZO]; // tied to the statement ("+v") so that its three selector dwords are formed here,
                             // not when v[ZO] is produced (that alone tripled the live registers)
-        asm volatile("ds_read_b128 %0, %5 offset:%c9\n\tds_read_b32 %1, %6 offset:%c10\n\t"
-                     "ds_read_b128 %2, %7 offset:%c9\n\tds_read_b32 %3, %8 offset:%c10\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(ta), "=&v"(tca), "=&v"(tb), "=&v"(tcb), "+v"(z)
-                     : "v"(la16), "v"(la4), "v"(lb16), "v"(lb4), "i"(LEAF0 * 16), "i"(LEAF0 * 4)
-                     : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.ta[P]), "+v"(R.tca[P]), "+v"(R.tb[P]), "+v"(R.tcb[P]), "+v"(z)::"memory"); // this leaf's tables have landed
+        if constexpr (LEAF0 + 1 < KLEAVES) leaf_issue<LEAF0 + 1, P ^ 1>(R, la16, la4, lb16, lb4);
+        const uint4_t ta = R.ta[P], tb = R.tb[P];
+        const unsigned tca = R.tca[P], tcb = R.tcb[P];
         const unsigned sa = z & 0x07070707u, sb = (z >> 3) & 0x07070707u, sc = (z >> 6) & 0x03030303u;
         ya[YO] ^= __builtin_amdgcn_perm(ta.y, ta.x, sa) ^ __builtin_amdgcn_perm(ta.w, ta.z, sb) ^ __builtin_amdgcn_perm(0u, tca, sc);
         yb[YO] ^= __builtin_amdgcn_perm(tb.y, tb.x, sa) ^ __builtin_amdgcn_perm(tb.w, tb.z, sb) ^ __builtin_amdgcn_perm(0u, tcb, sc);
@@ -68,14 +81,23 @@ __device__ __forceinline__ void acc_conv2(unsigned (&v)[2 * KN - 1], unsigned (&
         constexpr int H = N / 2, L3 = pow3(H);
 #pragma unroll
         for (int i = 0; i < H; ++i) { ya[YO + H + i] ^= ya[YO + i]; yb[YO + H + i] ^= yb[YO + i]; }
-        acc_conv2<H, ZO, YO, LEAF0>(v, ya, yb, la16, la4, lb16, lb4);
-        acc_conv2<H, ZO + H, YO, LEAF0 + L3>(v, ya, yb, la16, la4, lb16, lb4);
+        acc_conv2<H, ZO, YO, LEAF0>(v, ya, yb, la16, la4, lb16, lb4, R);
+        acc_conv2<H, ZO + H, YO, LEAF0 + L3>(v, ya, yb, la16, la4, lb16, lb4, R);
 #pragma unroll
         for (int i = 0; i < H; ++i) v[sbase(N) + i] = v[ZO + i] ^ v[ZO + H + i];
-        acc_conv2<H, sbase(N), YO + H, LEAF0 + 2 * L3>(v, ya, yb, la16, la4, lb16, lb4);
+        acc_conv2<H, sbase(N), YO + H, LEAF0 + 2 * L3>(v, ya, yb, la16, la4, lb16, lb4, R);
 #pragma unroll
         for (int i = 0; i < H; ++i) { ya[YO + H + i] ^= ya[YO + i]; yb[YO + H + i] ^= yb[YO + i]; }
     }
+}
+
+// one 16 x 16 block pair: issues the first leaf, walks the tree
+__device__ __forceinline__ void conv_block2(unsigned (&v)[2 * KN - 1], unsigned (&ya)[KN], unsigned (&yb)[KN], unsigned la16, unsigned la4,
+                                            unsigned lb16, unsigned lb4)
+{
+    LeafRegs R;
+    leaf_issue<0, 0>(R, la16, la4, lb16, lb4);
+    acc_conv2<KN, 0, 0, 0>(v, ya, yb, la16, la4, lb16, lb4, R);
 }
 
 // LDS of one encoder workgroup (256 threads): carved out of `ldsraw` (16-byte aligned, ENC128_LDS_BYTES)
@@ -189,8 +211,7 @@ __device__ __forceinline__ void gf_encode128_wg(const Enc128Args &a, int bx, uns
 #pragma unroll
             for (int i = 0; i < KN; ++i) p ^= v[i];
             const int b0 = (2 * tp) ^ cb, b1 = (2 * tp + 1) ^ cb;
-            acc_conv2<KN, 0, 0, 0>(v, y0, y1, lds_addr(lt16 + b0 * KLEAVES), lds_addr(lt4 + b0 * KLEAVES),
-                                   lds_addr(lt16 + b1 * KLEAVES), lds_addr(lt4 + b1 * KLEAVES));
+            conv_block2(v, y0, y1, lds_addr(lt16 + b0 * KLEAVES), lds_addr(lt4 + b0 * KLEAVES), lds_addr(lt16 + b1 * KLEAVES), lds_addr(lt4 + b1 * KLEAVES));
         }
         if (tp == 0) __hip_atomic_fetch_xor(&ysum[32][lane], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll

@@ -22,6 +22,7 @@ namespace sdrhip {
 namespace {
 
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
 #include "gf_encode128_body.h"
 // rows accumulated per wave: RB = 4, 6 or 8, a workgroup (4 waves) = 4 x RB rows of the same frames.  The
 // launch picks the smallest tile that covers the matrix in one workgroup row (24 erasures -> RB = 6): the
@@ -227,6 +228,7 @@ struct DecPlanArgs {
     uint8_t *block0_out;       // may be NULL
     int nframes;
     uint8_t *plan2;            // [nframes][DEC128_PLAN_BYTES] records for gf_decode128_kernel (NULL: dense path only)
+    int strict;                // ctx option dec_strict: deliver only what the reference's copy-back loop delivers (see the planner)
     int max_rows;              // the caller's promise (ctx option dec_max_rows): no frame carries more recovery blocks
     unsigned *stats;           // [0] += frames that broke the promise (they stay as received; sdrhip_ctx_get_counter)
 };
@@ -239,7 +241,7 @@ struct Dec128Plan {
     uint8_t rowidx[128];                      // recovery row r (block 128 + r) -> i (array order), 255 = not received
     uint8_t rpos[DEC128_MAXN];                // position of the i-th received recovery block
     uint8_t ydst[DEC128_MAXN];                // original restored by row t of the inverse (ascending)
-    uint8_t minv[DEC128_MAXN * DEC128_MAXN];  // Minv[t][i]
+    uint8_t minv[DEC128_MAXN * DEC128_MAXN];  // Minv[t][i] at [i][t % 4][t / 4]: the eight constants a wave (rows w, w + 4, ...) needs for syndrome i are 8 consecutive bytes
     int32_t n;                                // erased originals to restore here (0: none, or not this kernel's frame)
     int32_t m1;                               // cm256's DecodeM1: one recovery block, XOR of everything received
     int32_t maxrow;                           // highest recovery row among the received ones
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
     constexpr int K = 128;
     __shared__ uint8_t s_exp[512];
     __shared__ uint16_t s_log[256];
-    __shared__ uint8_t s_idx[K], s_x[K], s_y[K], s_rank[K];
+    __shared__ uint8_t s_idx[K], s_x[K], s_y[K], s_rank[K], s_rpos[K];
     __shared__ int s_cnt[K];
     __shared__ int s_lpx[K], s_lqx[K], s_lpy[K], s_lqy[K];
     __shared__ uint8_t s_linv[K * K]; // log of Minv[t][i] (a Cauchy inverse has no zero entry)
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
         dup |= s_cnt[q] > 1;
     }
     const bool is_rec = b >= K;
-    if (is_rec) { s_x[rrank] = (uint8_t)b; s_rank[p] = (uint8_t)rrank; }
+    if (is_rec) { s_x[rrank] = (uint8_t)b; s_rank[p] = (uint8_t)rrank; s_rpos[rrank] = (uint8_t)p; }
     if (s_cnt[p] == 0 && mrank < nrec) s_y[mrank] = (uint8_t)p; // erased originals, ascending (nmiss == nrec without repeats)
     __syncthreads();
 
@@ -356,6 +358,11 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
         }
         return;
     }
+    // Strict mode (ctx option dec_strict): the reference copies back only the descriptors [128 - recoveryCount, 128)
+    // (SDRdaemonFECBuffer.cpp:204-211: it relies on the recovery blocks arriving last); cm256 restores erased original t into the
+    // t-th recovery block in ARRAY order, so a block restored into a recovery block that sits further up in the array is never
+    // copied and the frame keeps a hole (zeros) there.  hole(t) = that case; by default every restored block is delivered.
+    const bool hole = a.strict && p < N && (int)s_rpos[p] < K - N;
     // destination of the recovered rows
     {
         int16_t pd = -1, zd = -1;
@@ -369,20 +376,22 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
     }
     if (syn) {
         // the syndrome kernel applies the N x N inverse itself: no N x 128 product matrix
-        if (p < N) pl->ydst[p] = s_y[p];
+        if (p < N) pl->ydst[p] = (uint8_t)(s_y[p] | (hole ? 0x80 : 0)); // (bit 7: a hole of strict mode, the block is written as zeros)
         if (N == 1) { if (p == 0) { pl->minv[0] = 1; pl->m1 = 1; } }
-        else for (int e = p; e < N * N; e += K) { const int t = e / N, i = e - t * N; pl->minv[t * DEC128_MAXN + i] = s_exp[s_linv[t * K + i]]; }
+        else for (int e = p; e < N * N; e += K) { const int t = e / N, i = e - t * N; pl->minv[i * DEC128_MAXN + (t & 3) * 8 + (t >> 2)] = s_exp[s_linv[t * K + i]]; }
         if (p == 0) pl->n = N;
         return;
     }
     uint8_t *coef = a.coef + (size_t)f * K * K;
     if (N == 1) { // DecodeM1: XOR of everything that was received
-        coef[p] = 1;
+        coef[p] = (a.strict && (int)s_rpos[0] < K - 1) ? 0 : 1;
         return;
     }
     for (int t = 0; t < N; ++t) {
         unsigned v;
-        if (is_rec) {
+        if (a.strict && (int)s_rpos[t] < K - N) {
+            v = 0; // (a hole of strict mode: the row restores zeros)
+        } else if (is_rec) {
             v = s_exp[s_linv[t * K + s_rank[p]]];
         } else {
             v = 0;
@@ -564,8 +573,7 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
             for (int i = 0; i < KN; ++i) p ^= v[i];
             if (pl->m1) continue; // (parity only)
             const int t0 = (2 * tp) ^ cb, t1 = (2 * tp + 1) ^ cb;
-            acc_conv2<KN, 0, 0, 0>(v, y0, y1, lds_addr(lt16 + t0 * KLEAVES), lds_addr(lt4 + t0 * KLEAVES),
-                                   lds_addr(lt16 + t1 * KLEAVES), lds_addr(lt4 + t1 * KLEAVES));
+            conv_block2(v, y0, y1, lds_addr(lt16 + t0 * KLEAVES), lds_addr(lt4 + t0 * KLEAVES), lds_addr(lt16 + t1 * KLEAVES), lds_addr(lt4 + t1 * KLEAVES));
         }
         if (N == 0) return; // (uniform)
         if (tp == 0) __hip_atomic_fetch_xor(&ysum[32][lane], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -608,10 +616,12 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
     const int nmine = (N - w + 3) >> 2; // rows w + 4 u < N
     for (int i = 0; i < N; ++i) {
         const Sel sl = make_sel(syn[i][lane]);
+        // the wave's (up to) eight constants for this syndrome: one 8-byte read instead of a byte read per product
+        const uint2_t mm = *reinterpret_cast<const uint2_t *>(&pl->minv[i * DEC128_MAXN + w * 8]);
 #pragma unroll
         for (int u = 0; u < DEC128_MAXN / 4; ++u) {
             if (u < nmine) {
-                const int m = pl->minv[(w + 4 * u) * DEC128_MAXN + i];
+                const unsigned m = ((u < 4 ? mm.x : mm.y) >> (8 * (u & 3))) & 0xffu;
                 acc[u] ^= mulc(sl, *reinterpret_cast<const uint4_t *>(&tab[m * 8]), tab[m * 8 + 4]);
             }
         }
@@ -620,9 +630,10 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
 #pragma unroll
         for (int u = 0; u < DEC128_MAXN / 4; ++u) {
             if (u < nmine) {
-                const int y = pl->ydst[w + 4 * u];
-                if (y >= 1) pay[(size_t)(y - 1) * 127] = acc[u];
-                else if (b0) b0[0] = acc[u];
+                const int yy = pl->ydst[w + 4 * u], y = yy & 0x7f;
+                const unsigned val = (yy & 0x80) ? 0u : acc[u]; // (strict mode: a block the reference's copy-back would miss stays a hole)
+                if (y >= 1) pay[(size_t)(y - 1) * 127] = val;
+                else if (b0) b0[0] = val;
             }
         }
     }
@@ -690,13 +701,13 @@ namespace sdrhip {
 
 hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices_dev,
                                          const uint8_t *explog, const uint8_t *tab, int nframes, uint8_t *payload_out,
-                                         size_t payload_frame_bytes, uint8_t *block0_out, int max_rows, unsigned *stats, hipStream_t stream)
+                                         size_t payload_frame_bytes, uint8_t *block0_out, int max_rows, int strict, unsigned *stats, hipStream_t stream)
 {
     if (nframes <= 0) return hipSuccess;
     if (max_rows < 1) max_rows = 1;
     if (max_rows > 128) max_rows = 128;
     DecPlanArgs p;
-    p.max_rows = max_rows; p.stats = stats;
+    p.max_rows = max_rows; p.stats = stats; p.strict = strict;
     p.rx = rx; p.rx_frame_bytes = rx_frame_bytes; p.indices = indices_dev; p.explog = explog;
     p.coef = d.coef; p.pmap = d.pmap; p.zmap = d.zmap; p.pdst = d.pdst; p.zdst = d.zdst; p.nrec = d.nrec;
     p.payload_out = payload_out; p.payload_frame_bytes = payload_frame_bytes; p.block0_out = block0_out; p.nframes = nframes;

@@ -204,6 +204,7 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
         else if (v == "dense") c->opt.dec_syndrome = 0;
         else return fail(SDRHIP_EINVAL, "ctx_set_option: dec_path must be syndrome or dense");
     } else if (k == "dec_max_rows" && isnum && num >= 1 && num <= 128) c->opt.dec_max_rows = (int)num;
+    else if (k == "dec_strict" && isnum && num <= 1) c->opt.dec_strict = (int)num;
     else return fail(SDRHIP_EINVAL, "ctx_set_option: unknown key or malformed value: %s=%s", key, value);
     return SDRHIP_OK;
 }

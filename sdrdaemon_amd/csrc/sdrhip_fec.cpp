@@ -108,7 +108,7 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
     {
         KTimer kt(c, SDRHIP_K_FEC_DECODE);
         e = launch_fec_decode_device_plan(d, rx, rx_frame_bytes, idx_dev, c->gf_explog, c->gf_tab, (int)nframes, payload_out,
-                                          payload_frame_bytes, block0_out, c->opt.dec_max_rows, c->dec_stats, c->stream);
+                                          payload_frame_bytes, block0_out, c->opt.dec_max_rows, c->opt.dec_strict, c->dec_stats, c->stream);
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec decode launch: %s", hipGetErrorString(e));
     return SDRHIP_OK;

@@ -112,6 +112,7 @@ struct CtxOptions {
     size_t interp_span = 0;
     int rx_fused = 1;                      // pipelined Rx pipe: encoder in the decimator's launch (0 = separate launches)
     int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)
+    int dec_strict = 0;                    // batched decode delivers only what the reference's copy-back loop delivers (SDRdaemonFECBuffer.cpp:204-211)
     int dec_max_rows = 128;                // upper bound of the recovery blocks a received frame can have used (the sender's fecblk)
 };
 // what the last decimate / rx call of a bank actually launched (sdrhip_decimators_last_plan)

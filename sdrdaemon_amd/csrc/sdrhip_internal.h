@@ -274,6 +274,6 @@ struct DecodeBuffers {
 // frame can have used (128 when unknown); a frame that carries more is left as received and counted in stats[0]
 hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices_dev,
                                          const uint8_t *explog, const uint8_t *tab, int nframes, uint8_t *payload_out,
-                                         size_t payload_frame_bytes, uint8_t *block0_out, int max_rows, unsigned *stats, hipStream_t stream);
+                                         size_t payload_frame_bytes, uint8_t *block0_out, int max_rows, int strict, unsigned *stats, hipStream_t stream);
 
 } // namespace sdrhip

