@@ -211,10 +211,26 @@ def timed_steps(ctx, fn, classes, steps=40, preroll_s=0.15):
     return wall, per
 
 
-def roof(bytes_per_launch, launch_ms, kernel):
+def pmc_traffic_units(kernel, units_key, units):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic.json), when the entry was collected on
+    the same number of units (outputs / samples) per launch; else None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)[kernel]
+        if int(t[units_key]) != int(units):
+            return None
+        return float(t["fetch_size_kb"]) * 1024.0 * float(t["fetch_correction"]) + float(t["write_size_kb"]) * 1024.0
+    except Exception:
+        return None
+
+
+def roof(bytes_per_launch, launch_ms, kernel, traffic=None):
     ach = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "kernel": kernel, "avg_launch_ms": round(launch_ms, 4), "traffic": None}
+    r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+         "kernel": kernel, "avg_launch_ms": round(launch_ms, 4), "traffic": traffic}
+    if traffic is not None:
+        r["traffic_source"] = "profiles/traffic.json (committed PMC passes of the same launch geometry; not measured by this run)"
+    return r
 
 
 def extra_configs(ctx, dev, x, kind):
@@ -230,7 +246,8 @@ def extra_configs(ctx, dev, x, kind):
     wall, per = timed_steps(ctx, lambda: d.decimate(LOG2DECIM, sd.FC_CEN, 16, x, out=y), [K_DECIMATE])
     out.append({"config": "configs[1]: %d streams x 2^%d samples, decimate16_cen (EO1), FEC off" % (S, n.bit_length() - 1),
                 "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
-                "roofline": roof(BYTES_DECIM * S * n, per[K_DECIMATE], decim_kernel_name(d.last_plan()))})
+                "roofline": roof(BYTES_DECIM * S * n, per[K_DECIMATE], decim_kernel_name(d.last_plan()),
+                                 pmc_traffic(float(S) * n, decim_kernel_name(d.last_plan())))})
     del y
     # the headline workload through the pipelined plumbing (sdrhip_rx_set_pipelined: frames delivered one call late, the encoder of
     # call i - 1 inside the decimator launch of call i).  Steady state: every timed step holds one decimation and one encode.
@@ -274,7 +291,8 @@ def extra_configs(ctx, dev, x, kind):
                           "blocks (a distinct random pattern per frame, %d distinct) + interpolate16_cen" % (Stx, F, len({k.tobytes() for k in keep})),
                 "ms_per_step": round(wall, 4), "value": round(nout / wall / 1e3, 1), "unit": "Msamples/s (output)",
                 "decode_ms_per_step": round(per[K_FEC_DECODE], 4),
-                "roofline": roof((4.0 + 4.0 / 16.0) * nout, per[K_INTERPOLATE], interp_kernel_name(ctx)),
+                "roofline": roof((4.0 + 4.0 / 16.0) * nout, per[K_INTERPOLATE], interp_kernel_name(ctx),
+                                 pmc_traffic_units(interp_kernel_name(ctx), "outputs_per_launch", nout)),
                 "pipe_gbps_config4": round((4.0 + 128.0 * 512.0 / 258064.0) * nout / (wall * 1e-3) / 1e9, 1),
                 "verified": tx_verified})
     return out

@@ -273,15 +273,17 @@ int sdrhip_rx_frames_view(const sdrhip_rx *rx, const uint8_t **base, size_t *str
  * (SDRHIP_MEM_HOST) and returns at once: the block is appended to a pinned staging buffer -- or used IN PLACE when it lies in
  * sdrhip_host_alloc memory, which the caller then leaves untouched until the batch is collected -- and every `blocks` blocks go
  * out as one upload + launch + download on the context's stream.  sdrhip_rx_collect returns the finished frames of the OLDEST
- * batch ((128 + nb_fec) super blocks per frame, stream s at frames_out + s * frame_stride_bytes; sdrhip_rx_max_frames() of the
- * batch's samples bounds them): wait = 0 returns SDRHIP_EBUSY while that batch is still in flight or being filled, wait = 1
+ * batch ((128 + nb_fec) super blocks per frame, stream s at frames_out + s * frame_stride_bytes; frames_out has room for
+ * max_frames frames per stream: a batch that holds more stays uncollected, *n_frames says how many, the call returns
+ * SDRHIP_EINVAL; sdrhip_rx_max_frames() of the batch's samples bounds them -- in pipelined mode a batch delivers the frames the
+ * PREVIOUS batch completed): wait = 0 returns SDRHIP_EBUSY while that batch is still in flight or being filled, wait = 1
  * blocks (a partly filled batch is launched as it is: end of stream).  At most `depth` batches are in flight; sdrhip_rx_submit
  * returns SDRHIP_EBUSY when the ring is full.  Defaults (no sdrhip_rx_set_async call): depth 4, one block per batch.  tv_sec /
  * tv_usec of a batch = those of its first block (frames are stamped by the sample clock from there, see sdrhip_rx_process).
  * Do not mix sdrhip_rx_process calls into a submit / collect sequence while batches are in flight. */
 int sdrhip_rx_set_async(sdrhip_rx *rx, int depth, int blocks);
 int sdrhip_rx_submit(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in, size_t in_stride, uint32_t tv_sec, uint32_t tv_usec);
-int sdrhip_rx_collect(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames, int wait);
+int sdrhip_rx_collect(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t max_frames, size_t *n_frames, int wait);
 /* Pinned host memory for the source side (the buffers a DeviceSource pushes): blocks submitted from it skip the staging copy. */
 void *sdrhip_host_alloc(sdrhip_ctx *ctx, size_t bytes);
 void sdrhip_host_free(sdrhip_ctx *ctx, void *p);

@@ -102,7 +102,7 @@ def load():
     lib.sdrhip_rx_flush.argtypes = [vp, vp, sz, C.POINTER(sz), i]
     lib.sdrhip_rx_set_async.argtypes = [vp, i, i]
     lib.sdrhip_rx_submit.argtypes = [vp, vp, sz, sz, C.c_uint32, C.c_uint32]
-    lib.sdrhip_rx_collect.argtypes = [vp, vp, sz, C.POINTER(sz), i]
+    lib.sdrhip_rx_collect.argtypes = [vp, vp, sz, sz, C.POINTER(sz), i]
     lib.sdrhip_host_alloc.argtypes = [vp, sz]
     lib.sdrhip_host_alloc.restype = vp
     lib.sdrhip_host_free.argtypes = [vp, vp]

@@ -34,7 +34,12 @@ template <int L> __global__ __launch_bounds__(NT) void interp_kernel(InterpArgs 
 }
 
 // K5w: one wave per workgroup, one time slice of one stream per wave, no barrier (interp_wave.h)
-template <int L> __global__ __launch_bounds__(WNT) void interp_wave_kernel(InterpArgs a)
+#ifdef W_WPE // (experiment: waves per SIMD the register allocator has to make room for)
+#define W_WPE_ATTR __attribute__((amdgpu_waves_per_eu(W_WPE, W_WPE)))
+#else
+#define W_WPE_ATTR
+#endif
+template <int L> __global__ __launch_bounds__(WNT) W_WPE_ATTR void interp_wave_kernel(InterpArgs a)
 {
     __shared__ __attribute__((aligned(16))) int lds[WGeo<(L == 6) ? 5 : L>::ldsDw];
     interp_wave_segment<L>(a, blockIdx.x, blockIdx.y, lds);

@@ -731,7 +731,7 @@ extern "C" int sdrhip_rx_submit(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in
     return SDRHIP_OK;
 }
 
-extern "C" int sdrhip_rx_collect(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames, int wait)
+extern "C" int sdrhip_rx_collect(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t max_frames, size_t *n_frames, int wait)
 {
     if (!rx || !n_frames) return fail(SDRHIP_EINVAL, "rx_collect: NULL argument");
     sdrhip::CtxLock lock_(rx->ctx);
@@ -754,6 +754,10 @@ extern "C" int sdrhip_rx_collect(sdrhip_rx *rx, uint8_t *frames_out, size_t fram
         HIP_TRY(hipEventSynchronize(b.done));
     }
     const int S = rx->nstreams;
+    if (b.frames > max_frames) { // (the batch stays where it is: call again with room for *n_frames frames per stream)
+        *n_frames = b.frames;
+        return fail(SDRHIP_EINVAL, "rx_collect: the batch holds %zu frames per stream, frames_out has room for %zu", b.frames, max_frames);
+    }
     if (b.frames) {
         if (!frames_out) return fail(SDRHIP_EINVAL, "rx_collect: NULL frames_out");
         const size_t row = b.frames * b.frame_bytes;

@@ -571,9 +571,14 @@ class RxPipe:
         filled (wait = False)"""
         cap = max_frames if max_frames is not None else max(getattr(self, "_async_cap", 0) // (SAMPLES_PER_FRAME << self.cfg.log2decim) + 2, 1)
         fb = (NB_ORIGINAL + self.nb_fec) * UDPSIZE
-        out = np.empty((self.nstreams, cap, NB_ORIGINAL + self.nb_fec, UDPSIZE), np.uint8)
         nf = C.c_size_t(0)
-        rc = self.ctx.lib.sdrhip_rx_collect(self.h, _ptr(out), cap * fb, C.byref(nf), 1 if wait else 0)
+        for _ in range(2):  # (a batch bigger than the guess -- pipelined mode delivers the previous batch's frames -- is asked for again)
+            out = np.empty((self.nstreams, cap, NB_ORIGINAL + self.nb_fec, UDPSIZE), np.uint8)
+            rc = self.ctx.lib.sdrhip_rx_collect(self.h, _ptr(out), cap * fb, cap, C.byref(nf), 1 if wait else 0)
+            if rc == -1 and nf.value > cap:
+                cap = nf.value
+                continue
+            break
         if rc == -6 and not wait:
             return None
         check(rc)

@@ -451,3 +451,24 @@ def test_rx_submit_collect_equals_the_synchronous_pipe(ctx, oracle, blocks, pinn
             assert np.array_equal(got[s, f, 128:], oracle.frame_encode(got[s, f, :128], 32)), (s, f)
     if pinned:
         ctx.host_free(src)
+
+
+def test_rx_collect_refuses_a_buffer_that_is_too_small(ctx):
+    """sdrhip_rx_collect knows the caller's capacity (max_frames): a batch that holds more frames stays uncollected, the count
+    comes back with SDRHIP_EINVAL, a second call with room gets the frames"""
+    import ctypes as C
+
+    import sdrdaemon_amd as sd
+
+    x = signals.noise(5 * 16129 * 16 + 100, 9)
+    rx = sd.RxPipe(ctx, 1, log2decim=4, nb_fec=8)
+    rx.set_async(depth=2, blocks=1)
+    rx.submit(x, 1, 2)
+    nf = C.c_size_t(0)
+    tiny = np.empty((1, 2, 136, 512), np.uint8)
+    rc = ctx.lib.sdrhip_rx_collect(rx.h, C.c_void_p(tiny.ctypes.data), 2 * 136 * 512, 2, C.byref(nf), 1)
+    assert rc == -1 and nf.value == 5
+    got = rx.collect(wait=True, max_frames=1)  # (the binding asks again with the reported count)
+    assert got.shape == (1, 5, 136, 512)
+    ref = sd.RxPipe(ctx, 1, log2decim=4, nb_fec=8).process(x, 1, 2)
+    assert np.array_equal(got[0], ref)

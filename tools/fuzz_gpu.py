@@ -109,6 +109,9 @@ while time.time() - t0 < budget:
         pipelined = bool(rs.rand() < 0.4)  # frames one call late (the encoder rides in the next call's decimator launch) + flush
         rx = sd.RxPipe(ctx, S, log2decim=L, fcpos=fc, hb_variant=bias, nb_fec=R, pipelined=pipelined)
         waiting = None  # pipelined: what the NEXT call (or the flush) has to deliver: (expected frames per stream, R)
+        use_async = bool(rs.rand() < 0.3)  # host calls through sdrhip_rx_submit + sdrhip_rx_collect (one block per batch)
+        if use_async:
+            rx.set_async(depth=2, blocks=1)
 
         def check(got, exp, Rexp, tag):
             for s in range(S):
@@ -142,6 +145,9 @@ while time.time() - t0 < budget:
                 xt = torch.zeros((S, (n_raw + 3) & ~3, 2), dtype=torch.int16, device="cuda")
                 xt[:, :n_raw] = torch.from_numpy(x).cuda()
                 got = rx.process_view(xt[:, :n_raw], tv_sec=k, tv_usec=it).torch().cpu().numpy().reshape(S, -1, 128 + R, 512)
+            elif use_async:
+                rx.submit(x, tv_sec=k, tv_usec=it)
+                got = rx.collect(wait=True, max_frames=(nd // 16129) + 3).reshape(S, -1, 128 + R, 512)
             else:
                 got = rx.process(x, tv_sec=k, tv_usec=it).reshape(S, -1, 128 + R, 512)
             exp = []
