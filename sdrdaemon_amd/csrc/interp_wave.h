@@ -20,6 +20,7 @@ namespace {
 
 constexpr int WNT = 64;          // one wave
 constexpr int WB = 128;          // inputs per block
+constexpr int WWARM = 44;        // warm-up of a segment, inputs: the cascade's memory is 43 (32 + 16 / 2 + 8 / 4 + 8 / 8 [+ 8 / 16]); even (packed pairs)
 constexpr int WCAP = 256;        // fresh entries a stage buffer (s >= 1) holds
 constexpr int WSTR = HIST + WCAP; // 288 dwords = 72 sixteen-byte slots = 8 mod 16: I / Q lane pairs of a ds_read_b128 group hit distinct banks
 constexpr int WPAIRS = 8;        // a segment's whole input (<= 2 x WPAIRS blocks) is loaded at the wave's start and parked in 4 x WPAIRS AGPRs
@@ -299,7 +300,7 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
     };
 
     size_t pos = seg_start;
-    if (seg != 0) single(seg_start - WARM, WARM, false); // histories of the slice from the 64 inputs in front of it, stores suppressed
+    if (seg != 0) single(seg_start - WWARM, WWARM, false); // histories of the slice from the 44 inputs in front of it, stores suppressed
     oc.store = true;
     for (int p = 0; p < npairs; ++p) {
         // the pair's 256 samples: lane t holds samples 4t .. 4t+3 -> packed dwords 2t, 2t+1 of both planes
