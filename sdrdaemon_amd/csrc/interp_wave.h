@@ -70,16 +70,30 @@ template <class G, bool FULL> __device__ __forceinline__ void wstage0(int *lds, 
         const uint2_t v = *reinterpret_cast<const uint2_t *>(pl + 2 * t);
         W[2 * t] = v.x; W[2 * t + 1] = v.y;
     }
-    unsigned A[18]; // the odd alignment: A[t] <-> entries 2t - 1, 2t of the window
-#pragma unroll
-    for (int t = 1; t < 18; ++t) A[t] = __builtin_amdgcn_alignbit(W[t], W[t - 1], 16);
     int acc[4] = {0, 0, 0, 0};
+    if constexpr (G::NS == 3) {
+        // interpolate8: the odd alignment A(t) <-> entries 2t - 1, 2t of the window is formed where it is used (twice each: 15 more
+        // v_perm per invocation, 17 fewer live registers: 56 + 32 -> five waves per SIMD, +3.4 %; the other ratios run faster with
+        // four, tools/experiments_r04/exp19.sh)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        acc[0] = wdot2(A[16 - e], tap_pair(e), acc[0]);
-        acc[1] = wdot2(W[16 - e], tap_pair(e), acc[1]);
-        acc[2] = wdot2(A[17 - e], tap_pair(e), acc[2]);
-        acc[3] = wdot2(W[17 - e], tap_pair(e), acc[3]);
+        for (int e = 0; e < 16; ++e) {
+            const unsigned a0 = __builtin_amdgcn_alignbit(W[16 - e], W[15 - e], 16), a2 = __builtin_amdgcn_alignbit(W[17 - e], W[16 - e], 16);
+            acc[0] = wdot2(a0, tap_pair(e), acc[0]);
+            acc[1] = wdot2(W[16 - e], tap_pair(e), acc[1]);
+            acc[2] = wdot2(a2, tap_pair(e), acc[2]);
+            acc[3] = wdot2(W[17 - e], tap_pair(e), acc[3]);
+        }
+    } else {
+        unsigned A[18]; // the odd alignment: A[t] <-> entries 2t - 1, 2t of the window
+#pragma unroll
+        for (int t = 1; t < 18; ++t) A[t] = __builtin_amdgcn_alignbit(W[t], W[t - 1], 16);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            acc[0] = wdot2(A[16 - e], tap_pair(e), acc[0]);
+            acc[1] = wdot2(W[16 - e], tap_pair(e), acc[1]);
+            acc[2] = wdot2(A[17 - e], tap_pair(e), acc[2]);
+            acc[3] = wdot2(W[17 - e], tap_pair(e), acc[3]);
+        }
     }
     // v[2m] = u[m - 16]: entries 16 .. 19 of the window
     o[0] = (int)(short)(W[8] & 0xffffu); o[2] = (int)W[8] >> 16; o[4] = (int)(short)(W[9] & 0xffffu); o[6] = (int)W[9] >> 16;
