@@ -276,8 +276,10 @@ int sdrhip_rx_frames_view(const sdrhip_rx *rx, const uint8_t **base, size_t *str
  * batch ((128 + nb_fec) super blocks per frame, stream s at frames_out + s * frame_stride_bytes; frames_out has room for
  * max_frames frames per stream: a batch that holds more stays uncollected, *n_frames says how many, the call returns
  * SDRHIP_EINVAL; sdrhip_rx_max_frames() of the batch's samples bounds them -- in pipelined mode a batch delivers the frames the
- * PREVIOUS batch completed): wait = 0 returns SDRHIP_EBUSY while that batch is still in flight or being filled, wait = 1
- * blocks (a partly filled batch is launched as it is: end of stream).  At most `depth` batches are in flight; sdrhip_rx_submit
+ * PREVIOUS batch completed).  SDRHIP_OK always means: ONE batch was collected (*n_frames of it, possibly 0: blocks shorter than a
+ * frame); SDRHIP_EBUSY: none was -- nothing submitted, or (wait = 0) the oldest batch is still in flight or being filled; wait = 1
+ * blocks, outside the context lock (another thread may go on submitting), and launches a partly filled batch as it is (end of
+ * stream).  At most `depth` batches are in flight; sdrhip_rx_submit
  * returns SDRHIP_EBUSY when the ring is full.  Defaults (no sdrhip_rx_set_async call): depth 4, one block per batch.  tv_sec /
  * tv_usec of a batch = those of its first block (frames are stamped by the sample clock from there, see sdrhip_rx_process).
  * Do not mix sdrhip_rx_process calls into a submit / collect sequence while batches are in flight. */

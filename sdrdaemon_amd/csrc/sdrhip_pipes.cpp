@@ -734,25 +734,36 @@ extern "C" int sdrhip_rx_submit(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in
 extern "C" int sdrhip_rx_collect(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t max_frames, size_t *n_frames, int wait)
 {
     if (!rx || !n_frames) return fail(SDRHIP_EINVAL, "rx_collect: NULL argument");
-    sdrhip::CtxLock lock_(rx->ctx);
+    // (the wait for a batch happens OUTSIDE the context lock: the submitting thread -- the reference's source / main thread -- keeps
+    // feeding the ring while the collecting thread -- its transmit thread -- sleeps on the oldest batch's event)
+    std::unique_lock<std::recursive_mutex> lock_(rx->ctx->mtx);
     *n_frames = 0;
-    if (rx->abatch.empty()) return SDRHIP_OK;
+    if (rx->abatch.empty()) return fail(SDRHIP_EBUSY, "rx_collect: nothing was submitted");
     HIP_TRY(hipSetDevice(rx->ctx->device));
-    sdrhip_rx::Batch &b = rx->abatch[rx->a_head % rx->abatch.size()];
-    if (b.state == 0) return SDRHIP_OK; // nothing submitted
-    if (b.state == 1) {
-        if (!wait) return fail(SDRHIP_EBUSY, "rx_collect: the oldest batch is still being filled (wait = 1 launches it as it is)");
-        int rc = rx_launch_batch(rx, b); // a partly filled batch goes out as it is (end of stream)
-        if (rc) return rc;
-        ++rx->a_tail;
+    sdrhip_rx::Batch *bp = nullptr;
+    for (;;) {
+        sdrhip_rx::Batch &h = rx->abatch[rx->a_head % rx->abatch.size()];
+        if (h.state == 0) return fail(SDRHIP_EBUSY, "rx_collect: nothing was submitted"); // (SDRHIP_OK always means: one batch collected, *n_frames of it -- possibly 0)
+        if (h.state == 1) {
+            if (!wait) return fail(SDRHIP_EBUSY, "rx_collect: the oldest batch is still being filled (wait = 1 launches it as it is)");
+            int rc = rx_launch_batch(rx, h); // a partly filled batch goes out as it is (end of stream)
+            if (rc) return rc;
+            ++rx->a_tail;
+        }
+        const hipError_t q = hipEventQuery(h.done);
+        if (q == hipSuccess) { bp = &h; break; }
+        if (q != hipErrorNotReady) return fail(SDRHIP_EDEVICE, "hipEventQuery: %s", hipGetErrorString(q));
+        if (!wait) return fail(SDRHIP_EBUSY, "rx_collect: the oldest batch is still in flight");
+        const size_t head = rx->a_head;
+        hipEvent_t ev = h.done;
+        lock_.unlock();
+        const hipError_t w = hipEventSynchronize(ev);
+        lock_.lock();
+        if (w != hipSuccess) return fail(SDRHIP_EDEVICE, "hipEventSynchronize: %s", hipGetErrorString(w));
+        if (rx->a_head == head) { bp = &rx->abatch[head % rx->abatch.size()]; break; }
+        // (another thread collected that batch meanwhile: look at the new head)
     }
-    if (!wait) {
-        const hipError_t q = hipEventQuery(b.done);
-        if (q == hipErrorNotReady) return fail(SDRHIP_EBUSY, "rx_collect: the oldest batch is still in flight");
-        if (q != hipSuccess) return fail(SDRHIP_EDEVICE, "hipEventQuery: %s", hipGetErrorString(q));
-    } else {
-        HIP_TRY(hipEventSynchronize(b.done));
-    }
+    sdrhip_rx::Batch &b = *bp;
     const int S = rx->nstreams;
     if (b.frames > max_frames) { // (the batch stays where it is: call again with room for *n_frames frames per stream)
         *n_frames = b.frames;

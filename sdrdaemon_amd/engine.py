@@ -567,8 +567,8 @@ class RxPipe:
         check(self.ctx.lib.sdrhip_rx_submit(self.h, _ptr(x), x.shape[1], _stride_samples(x), tv_sec, tv_usec))
 
     def collect(self, wait=True, max_frames=None):
-        """-> the finished frames of the oldest batch (S, n, 128 + nb_fec, 512), or None while it is still in flight / being
-        filled (wait = False)"""
+        """-> the finished frames of the oldest batch (S, n, 128 + nb_fec, 512; n may be 0), or None when no batch was collected:
+        nothing submitted, or (wait = False) the oldest batch is still in flight / being filled"""
         cap = max_frames if max_frames is not None else max(getattr(self, "_async_cap", 0) // (SAMPLES_PER_FRAME << self.cfg.log2decim) + 2, 1)
         fb = (NB_ORIGINAL + self.nb_fec) * UDPSIZE
         nf = C.c_size_t(0)
@@ -579,7 +579,7 @@ class RxPipe:
                 cap = nf.value
                 continue
             break
-        if rc == -6 and not wait:
+        if rc == -6:
             return None
         check(rc)
         return out[:, :nf.value]
