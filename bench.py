@@ -300,7 +300,7 @@ def extra_configs(ctx, dev, x, kind):
 
 def interp_kernel_name(ctx):
     """interpolate16_cen: K5w (interp_wave.h) unless the context was told otherwise (SDRHIP_INTERP_PATH = valu: K5)"""
-    return "interp_kernel<4>" if os.environ.get("SDRHIP_INTERP_PATH", "auto") == "valu" else "interp_wave_kernel<4>"
+    return "interp_kernel<4>" if os.environ.get("SDRHIP_INTERP_PATH", "auto") == "valu" else "interp_wave_kernel<4, 4>"
 
 
 def verify_tx_step(ctx, rxf, kind, n):

@@ -33,21 +33,27 @@ template <int L> __global__ __launch_bounds__(NT) void interp_kernel(InterpArgs 
     interp_segment<L>(a, blockIdx.x, blockIdx.y, lds);
 }
 
-// K5w: one wave per workgroup, one time slice of one stream per wave, no barrier (interp_wave.h)
-#ifdef W_WPE // (experiment: waves per SIMD the register allocator has to make room for)
-#define W_WPE_ATTR __attribute__((amdgpu_waves_per_eu(W_WPE, W_WPE)))
-#else
-#define W_WPE_ATTR
-#endif
-template <int L> __global__ __launch_bounds__(WNT) W_WPE_ATTR void interp_wave_kernel(InterpArgs a)
+// K5w: one time slice of one stream per wave, no barrier (interp_wave.h)
+// WPW waves per workgroup, each on a segment of its own (no barrier, no shared data: a workgroup is only a way of starting WPW
+// waves at the same moment, which puts their clusters of input loads at the same moment -- see interp_wave_segment; measured
+// 6 % on interpolate32, 0..1 % on the others, tools/experiments_r04 batch 20).  Launches too small to fill the chip with
+// workgroups of four keep one wave per workgroup.
+template <int L, int WPW> __global__ __launch_bounds__(WNT * WPW) void interp_wave_kernel(InterpArgs a)
 {
-    __shared__ __attribute__((aligned(16))) int lds[WGeo<(L == 6) ? 5 : L>::ldsDw];
-    interp_wave_segment<L>(a, blockIdx.x, blockIdx.y, lds);
+    __shared__ __attribute__((aligned(16))) int lds[WPW][WGeo<(L == 6) ? 5 : L>::ldsDw];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int seg = (int)blockIdx.x * WPW + w;
+    if (seg >= a.nseg) return;
+    interp_wave_segment<L>(a, seg, blockIdx.y, lds[w]);
 }
 
 template <int L> hipError_t launch_w(const InterpArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((interp_wave_kernel<L>), dim3(a.nseg, a.nstreams), dim3(WNT), 0, stream, a);
+    constexpr int WPW = 4;
+    if ((size_t)a.nseg * (size_t)a.nstreams >= 4096)
+        hipLaunchKernelGGL((interp_wave_kernel<L, WPW>), dim3((a.nseg + WPW - 1) / WPW, a.nstreams), dim3(WNT * WPW), 0, stream, a);
+    else
+        hipLaunchKernelGGL((interp_wave_kernel<L, 1>), dim3(a.nseg, a.nstreams), dim3(WNT), 0, stream, a);
     return hipGetLastError();
 }
 

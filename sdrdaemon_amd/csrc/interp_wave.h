@@ -2,7 +2,7 @@
 //
 // Same arithmetic as interp_body.h (Interpolators::interpolate{4..64}_cen over IntHalfbandFilterEO1/DB<64|32|16>::myInterpolate,
 // Interpolators.cpp:47-606, IntHalfbandFilterEO1.h:44-65,149-168), different machine mapping:
-//  * a workgroup IS one wave (64 lanes) that owns a time slice of one stream and its own 7.5 KB of LDS: no s_barrier anywhere
+//  * a wave (64 lanes; a workgroup is one wave or four independent ones) owns a time slice of one stream and its own 7.5 KB of LDS: no s_barrier anywhere
 //    (K5 needs 20 workgroup barriers per macro-cycle); the stage buffers are handed from stage to stage by the wave itself, LDS
 //    operations of one wave execute in order, so a write followed by a read needs no synchronisation at all;
 //  * blocks of 128 inputs, walked depth first: stage s takes 128 inputs per invocation (lanes 2j / 2j+1 = I / Q of inputs
@@ -253,7 +253,7 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
     constexpr int NS = (L == 6) ? 5 : L;
     static_assert(NS >= 2, "interpolate2 has a single stage: K5");
     using G = WGeo<NS>;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const unsigned *in = reinterpret_cast<const unsigned *>(a.in) + (size_t)stream * a.in_stride;
     const size_t seg_len = (size_t)a.nsub_per_seg * WB;
     const size_t seg_start = (size_t)seg * seg_len;

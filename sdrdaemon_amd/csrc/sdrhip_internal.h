@@ -181,7 +181,7 @@ struct InterpArgs {
 };
 hipError_t launch_interpolate(int log2interp, const InterpArgs &a, hipStream_t stream);
 void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_seg, int *nseg);
-// K5w (interp_wave.h): one-wave workgroups, blocks of 128 inputs; log2interp 2..6
+// K5w (interp_wave.h): wave-private pipelines (workgroups of one or four independent waves), blocks of 128 inputs; log2interp 2..6
 void plan_interpolate_wave(int log2interp, size_t n_in, int nstreams, int n_cu, size_t seg_override, int *nsub_per_seg, int *nseg);
 hipError_t launch_interpolate_wave(int log2interp, const InterpArgs &a, hipStream_t stream);
 bool plan_interpolate_mfma(int log2interp, size_t n_in, int nstreams, size_t span_override, InterpArgs *a);

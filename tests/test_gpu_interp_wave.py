@@ -110,3 +110,23 @@ def test_stream_bank_device_memory(ctx, oracle, path):
             y = y.cpu().numpy()
             for s in range(S):
                 assert np.array_equal(y[s], ous[s].interpolate(log2, x[s, part])), (log2, s)
+
+
+def test_four_wave_workgroups_ragged_tail(ctx, oracle, path):
+    """launches of >= 4096 segments run K5w as workgroups of four independent waves; a segment count that is not a multiple of
+    four (1370 per stream, three streams, 128-input segments) leaves the last workgroup two idle waves"""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    path(128)
+    S, n = 3, 128 * 1369 + 5
+    x = np.stack([signals.noise(n, 900 + s) for s in range(S)])
+    xd = torch.from_numpy(x).cuda()
+    for log2 in (2, 5):
+        u = sd.Interpolators(ctx, S)
+        y = u.interpolate(log2, xd)
+        ctx.synchronize()
+        y = y.cpu().numpy()
+        for s in range(S):
+            assert np.array_equal(y[s], oracle.interpolators().interpolate(log2, x[s])), (log2, s)
