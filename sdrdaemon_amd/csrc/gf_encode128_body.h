@@ -113,15 +113,15 @@ __device__ __forceinline__ void gf_encode128_wg(const Enc128Args &a, int bx, uns
     unsigned *rt4 = reinterpret_cast<unsigned *>(ldsraw + 8 * KLEAVES * 20 + 128 * 16);
     unsigned (*ysum)[64] = reinterpret_cast<unsigned (*)[64]>(ldsraw + 8 * KLEAVES * 20 + 128 * 20); // reduced convolution (32 rows) + parity (row 32)
     const int tid = threadIdx.x;
-    for (int i = tid; i < 8 * KLEAVES; i += GF_NT) {
-        const unsigned *src = reinterpret_cast<const unsigned *>(a.leaf_tables) + (size_t)i * 8;
-        lt16[i] = (uint4_t){src[0], src[1], src[2], src[3]};
-        lt4[i] = src[4];
+    for (int i = tid; i < 8 * KLEAVES; i += GF_NT) { // (32-byte table records: whole 16-byte loads)
+        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.leaf_tables) + (size_t)i * 2;
+        lt16[i] = src[0];
+        lt4[i] = reinterpret_cast<const unsigned *>(src + 1)[0];
     }
     if (tid < 128) {
-        const unsigned *src = reinterpret_cast<const unsigned *>(a.tab) + (size_t)tid * 8;
-        rt16[tid] = (uint4_t){src[0], src[1], src[2], src[3]};
-        rt4[tid] = src[4];
+        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.tab) + (size_t)tid * 2;
+        rt16[tid] = src[0];
+        rt4[tid] = reinterpret_cast<const unsigned *>(src + 1)[0];
     }
     for (int i = tid; i < 33 * 64; i += GF_NT) (&ysum[0][0])[i] = 0;
     __syncthreads();

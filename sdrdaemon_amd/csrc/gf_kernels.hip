@@ -261,6 +261,7 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
     __shared__ uint8_t s_linv[K * K]; // log of Minv[t][i] (a Cauchy inverse has no zero entry)
     __shared__ uint8_t s_le[K * K];   // log of (y'_p ^ x_0) / (x_i ^ y'_p) at [i][p]
     __shared__ int s_bad;
+    __shared__ unsigned long long s_mask[2][3];
     const int f = blockIdx.x, p = threadIdx.x;
     for (int i = p; i < 512; i += K) s_exp[i] = a.explog[i];
     for (int i = p; i < 256; i += K) s_log[i] = reinterpret_cast<const uint16_t *>(a.explog + 512)[i];
@@ -271,17 +272,17 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
     __syncthreads();
     if (b < K) atomicAdd(&s_cnt[b], 1);
     __syncthreads();
-    // ranks: of this position among the recovery blocks (array order), of original index p among the missing ones
-    int rrank = 0, nrec = 0, mrank = 0, nmiss = 0, dup = 0;
-    for (int q = 0; q < K; ++q) {
-        const int r = s_idx[q] >= K;
-        nrec += r;
-        rrank += r && q < p;
-        const int m = s_cnt[q] == 0;
-        nmiss += m;
-        mrank += m && q < p;
-        dup |= s_cnt[q] > 1;
-    }
+    // ranks: of this position among the recovery blocks (array order), of original index p among the missing ones -- population
+    // counts of the two waves' ballots below the lane (a 128-step scan of LDS per thread before round 4: a third of this kernel)
+    const int wv = p >> 6, ln = p & 63;
+    const unsigned long long br = __ballot(b >= K), bm = __ballot(s_cnt[p] == 0), bd = __ballot(s_cnt[p] > 1);
+    if (ln == 0) { s_mask[wv][0] = br; s_mask[wv][1] = bm; s_mask[wv][2] = bd; }
+    __syncthreads();
+    const unsigned long long below = (1ull << ln) - 1ull;
+    const int nrec = __popcll(s_mask[0][0]) + __popcll(s_mask[1][0]), nmiss = __popcll(s_mask[0][1]) + __popcll(s_mask[1][1]);
+    const int rrank = (wv ? __popcll(s_mask[0][0]) : 0) + __popcll(br & below);
+    const int mrank = (wv ? __popcll(s_mask[0][1]) : 0) + __popcll(bm & below);
+    const int dup = (s_mask[0][2] | s_mask[1][2]) != 0ull;
     const bool is_rec = b >= K;
     if (is_rec) { s_x[rrank] = (uint8_t)b; s_rank[p] = (uint8_t)rrank; s_rpos[rrank] = (uint8_t)p; }
     if (s_cnt[p] == 0 && mrank < nrec) s_y[mrank] = (uint8_t)p; // erased originals, ascending (nmiss == nrec without repeats)
@@ -522,14 +523,15 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
     Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4 + DEC128_MAXN * 64 * 4);
     const int tid = threadIdx.x;
     const int fr = blockIdx.x >> 1;
+    // (tables and plan records are 32- / 16-byte aligned: whole 16-byte loads, all of them in flight before the first LDS store)
     for (int i = tid; i < 8 * KLEAVES; i += GF_NT) {
-        const unsigned *src = reinterpret_cast<const unsigned *>(a.leaf_tables) + (size_t)i * 8;
-        lt16[i] = (uint4_t){src[0], src[1], src[2], src[3]};
-        lt4[i] = src[4];
+        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.leaf_tables) + (size_t)i * 2;
+        lt16[i] = src[0];
+        lt4[i] = reinterpret_cast<const unsigned *>(src + 1)[0];
     }
-    for (int i = tid; i < 256 * 8; i += GF_NT) tab[i] = reinterpret_cast<const unsigned *>(a.tab)[i];
-    for (int i = tid; i < DEC128_PLAN_BYTES / 4; i += GF_NT)
-        reinterpret_cast<unsigned *>(pl)[i] = reinterpret_cast<const unsigned *>(a.plan + (size_t)fr * DEC128_PLAN_BYTES)[i];
+    for (int i = tid; i < 256 * 2; i += GF_NT) reinterpret_cast<uint4_t *>(tab)[i] = reinterpret_cast<const uint4_t *>(a.tab)[i];
+    for (int i = tid; i < DEC128_PLAN_BYTES / 16; i += GF_NT)
+        reinterpret_cast<uint4_t *>(pl)[i] = reinterpret_cast<const uint4_t *>(a.plan + (size_t)fr * DEC128_PLAN_BYTES)[i];
     for (int i = tid; i < 33 * 64; i += GF_NT) (&ysum[0][0])[i] = 0;
     __syncthreads();
 
@@ -576,6 +578,19 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
             conv_block2(v, y0, y1, lds_addr(lt16 + t0 * KLEAVES), lds_addr(lt4 + t0 * KLEAVES), lds_addr(lt16 + t1 * KLEAVES), lds_addr(lt4 + t1 * KLEAVES));
         }
         if (N == 0) return; // (uniform)
+        // the recovery rows this wave turns into syndromes (rows 32 tp + 8 w .. + 7, those that arrived): their loads go out here, in
+        // front of the reduction and its barrier, not behind it (the phase was three dependent round trips: rowidx -> rpos -> HBM)
+        int ri[8];
+        unsigned rec[8];
+        if (!pl->m1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 32 * tp + 8 * w + q;
+                const int i = pl->rowidx[r & 127];
+                ri[q] = (r < 128 && i != 255) ? i : -1;
+                rec[q] = (ri[q] >= 0 && live) ? SDRHIP_STREAM_LOAD(rx + (size_t)pl->rpos[ri[q] & 31] * 128) : 0u;
+            }
+        }
         if (tp == 0) __hip_atomic_fetch_xor(&ysum[32][lane], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!pl->m1) {
 #pragma unroll
@@ -593,11 +608,9 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int rl = 8 * w + q, r = 32 * tp + rl;
-                const int i = pl->rowidx[r & 127];
-                if (r < 128 && i != 255) {
+                if (ri[q] >= 0) {
                     const uint4_t t = *reinterpret_cast<const uint4_t *>(&tab[r * 8]);
-                    const unsigned rec = live ? SDRHIP_STREAM_LOAD(rx + (size_t)pl->rpos[i] * 128) : 0u;
-                    syn[i][lane] = rec ^ P ^ kmul(ysum[rl][lane], t, tab[r * 8 + 4]);
+                    syn[ri[q]][lane] = rec[q] ^ P ^ kmul(ysum[rl][lane], t, tab[r * 8 + 4]);
                 }
             }
         }
@@ -614,17 +627,42 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
 #pragma unroll
     for (int u = 0; u < DEC128_MAXN / 4; ++u) acc[u] = 0u;
     const int nmine = (N - w + 3) >> 2; // rows w + 4 u < N
-    for (int i = 0; i < N; ++i) {
-        const Sel sl = make_sel(syn[i][lane]);
-        // the wave's (up to) eight constants for this syndrome: one 8-byte read instead of a byte read per product
-        const uint2_t mm = *reinterpret_cast<const uint2_t *>(&pl->minv[i * DEC128_MAXN + w * 8]);
+    // four syndromes at a time, the next four (and the wave's constants for them: one 8-byte read per syndrome instead of a byte
+    // read per product) already on their way from LDS: per syndrome the loop was two dependent LDS round trips (constants ->
+    // table addresses -> tables), 24 times over = three quarters of this phase (tools/experiments_r04/dec_stamps.py)
+    constexpr int CH = 4;
+    unsigned sy[CH];
+    uint2_t mc[CH];
 #pragma unroll
-        for (int u = 0; u < DEC128_MAXN / 4; ++u) {
-            if (u < nmine) {
-                const unsigned m = ((u < 4 ? mm.x : mm.y) >> (8 * (u & 3))) & 0xffu;
-                acc[u] ^= mulc(sl, *reinterpret_cast<const uint4_t *>(&tab[m * 8]), tab[m * 8 + 4]);
+    for (int k = 0; k < CH; ++k) {
+        sy[k] = syn[k][lane];
+        mc[k] = *reinterpret_cast<const uint2_t *>(&pl->minv[k * DEC128_MAXN + w * 8]);
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < N; i0 += CH) {
+        unsigned syn_next[CH];
+        uint2_t mc_next[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int i = (i0 + CH + k) & (DEC128_MAXN - 1); // (past the end: rows that exist and are not used)
+            syn_next[k] = syn[i][lane];
+            mc_next[k] = *reinterpret_cast<const uint2_t *>(&pl->minv[i * DEC128_MAXN + w * 8]);
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            if (i0 + k < N) {
+                const Sel sl = make_sel(sy[k]);
+#pragma unroll
+                for (int u = 0; u < DEC128_MAXN / 4; ++u) {
+                    if (u < nmine) {
+                        const unsigned m = ((u < 4 ? mc[k].x : mc[k].y) >> (8 * (u & 3))) & 0xffu;
+                        acc[u] ^= mulc(sl, *reinterpret_cast<const uint4_t *>(&tab[m * 8]), tab[m * 8 + 4]);
+                    }
+                }
             }
         }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) { sy[k] = syn_next[k]; mc[k] = mc_next[k]; }
     }
     if (live) {
 #pragma unroll
