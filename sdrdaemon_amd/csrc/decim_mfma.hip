@@ -618,6 +618,13 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
             if (wps1 >= 1) {
                 size_t S1 = n / (8 * wps1) / W * W;
                 if (S1 == 0 || n / (8 * S1) > wps1) S1 += W; // (rounding down must not add a wave)
+                // long periods (decimate32 / 64: W = 2048 / 4096) make that rounding coarse: one period less per span and a few
+                // waves more than 31 CUs per XCD hold -- they land on the 32nd -- costs ~3 %, a period more of span + warm-up per
+                // wave costs W / (S + W) (profiles/r04_decim_paths.txt: decimate64 0.2751 -> 0.2533 ms, decimate32 0.2513 -> 0.2447)
+                if (S1 > 8 * W) {
+                    const size_t S0 = S1 - W, wps0 = n / (8 * S0);
+                    if (wps0 * (size_t)nstreams <= (size_t)4 * (size_t)n_cu && (S0 + W) * 105 < (S1 + W) * 100) S1 = S0;
+                }
                 if (S1 <= 256 * W) S = S1;
             }
         }

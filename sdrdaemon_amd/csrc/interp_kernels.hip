@@ -80,11 +80,12 @@ void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_s
 // its start), an even number of them (the input comes back a PAIR of blocks at a time; an odd rest runs the guarded path)
 void plan_interpolate_wave(int log2interp, size_t n_in, int nstreams, int n_cu, size_t seg_override, int *nsub_per_seg, int *nseg)
 {
-    (void)log2interp; (void)nstreams; (void)n_cu;
+    (void)nstreams; (void)n_cu;
+    const size_t maxper = 2 * (size_t)wpairs(log2interp);
     size_t nsub = (n_in + WB - 1) / WB;
     if (nsub == 0) nsub = 1;
-    size_t per = seg_override ? (seg_override + WB - 1) / WB : 2 * WPAIRS;
-    if (per > 2 * WPAIRS) per = 2 * WPAIRS;
+    size_t per = seg_override ? (seg_override + WB - 1) / WB : maxper;
+    if (per > maxper) per = maxper;
     if (per > 1) per &= ~(size_t)1;
     if (per < 1) per = 1;
     *nsub_per_seg = (int)per;
