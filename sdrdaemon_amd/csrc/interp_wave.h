@@ -229,12 +229,16 @@ template <class G, int S, bool FULL> __device__ __forceinline__ void wdescend(in
 }
 
 // bank state <-> LDS (same record as K5: per stage 2 planes x 32 int32 entries; stage 0 lives packed here)
-template <class G, int S = 0> __device__ __forceinline__ void wstate_load(int *lds, int lane, const int32_t *st, bool zero)
+template <class G, int S = 0> __device__ __forceinline__ void wstate_fetch(int (&sv)[G::NS], int lane, const int32_t *st, bool zero)
 {
-    const int v = zero ? 0 : st[S * 2 * INT_HIST + lane];
-    if constexpr (S == 0) reinterpret_cast<short *>(lds + (lane >> 5) * W0STR)[lane & 31] = (short)v;
-    else lds[G::base(S) + (lane >> 5) * WSTR + (lane & 31)] = v;
-    if constexpr (S + 1 < G::NS) wstate_load<G, S + 1>(lds, lane, st, zero);
+    sv[S] = zero ? 0 : st[S * 2 * INT_HIST + lane];
+    if constexpr (S + 1 < G::NS) wstate_fetch<G, S + 1>(sv, lane, st, zero);
+}
+template <class G, int S = 0> __device__ __forceinline__ void wstate_put(int *lds, int lane, const int (&sv)[G::NS])
+{
+    if constexpr (S == 0) reinterpret_cast<short *>(lds + (lane >> 5) * W0STR)[lane & 31] = (short)sv[S];
+    else lds[G::base(S) + (lane >> 5) * WSTR + (lane & 31)] = sv[S];
+    if constexpr (S + 1 < G::NS) wstate_put<G, S + 1>(lds, lane, sv);
 }
 template <class G, int S = 0> __device__ __forceinline__ void wstate_store(const int *lds, int lane, int32_t *st)
 {
@@ -269,6 +273,9 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
     const bool al16 = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
     const int npairs = al16 ? (int)((seg_end - seg_start) / (2 * WB) < (size_t)WPAIRS ? (seg_end - seg_start) / (2 * WB) : (size_t)WPAIRS) : 0;
     unsigned A[4 * WPAIRS];
+    const int32_t *stc = a.state_cur + (size_t)stream * INT_STATE_WORDS;
+    uint2_t wv = (uint2_t){0u, 0u};
+    int sv[NS];
     {
         uint4_t v[WPAIRS];
 #pragma unroll
@@ -276,14 +283,21 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
             v[p] = (uint4_t){0u, 0u, 0u, 0u};
             if (p < npairs) v[p] = SDRHIP_STREAM_LOAD(reinterpret_cast<const uint4_t *>(in + seg_start + (size_t)p * 2 * WB + 4 * lane));
         }
+        // the warm-up's samples and the bank state: behind the cluster and in flight with it (three round trips in a row --
+        // cluster, state, warm-up -- at the start of every wave before; tools/experiments_r04 batch 24)
+        if (seg != 0) {
+            const unsigned *wp = in + (seg_start - WWARM) + 2 * lane;
+            if (2 * lane < WWARM) wv.x = SDRHIP_STREAM_LOAD(wp);
+            if (2 * lane + 1 < WWARM) wv.y = SDRHIP_STREAM_LOAD(wp + 1);
+        }
+        wstate_fetch<G>(sv, lane, stc, seg != 0);
 #pragma unroll
         for (int p = 0; p < WPAIRS; ++p)
             asm volatile("v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
                          : "=a"(A[4 * p]), "=a"(A[4 * p + 1]), "=a"(A[4 * p + 2]), "=a"(A[4 * p + 3]) : "v"(v[p].x), "v"(v[p].y), "v"(v[p].z), "v"(v[p].w));
     }
 
-    const int32_t *stc = a.state_cur + (size_t)stream * INT_STATE_WORDS;
-    wstate_load<G>(lds, lane, stc, seg != 0);
+    wstate_put<G>(lds, lane, sv);
     wave_sync();
 
     IOut oc;
@@ -304,11 +318,7 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
     };
     // ---- one block at a time with its own loads and every guard: the warm-up of a segment (in front of every store of the
     // wave), and what the pairs do not cover -- an odd block, a ragged end, an unaligned input: the last segment of a call
-    auto single = [&](size_t pos, int cnt, bool store) {
-        const int m = 2 * lane;
-        uint2_t v = (uint2_t){0u, 0u};
-        if (m < cnt) v.x = SDRHIP_STREAM_LOAD(in + pos + m);
-        if (m + 1 < cnt) v.y = SDRHIP_STREAM_LOAD(in + pos + m + 1);
+    auto single_v = [&](uint2_t v, int cnt, bool store) {
         p0[W0HIST + lane] = __builtin_amdgcn_perm(v.y, v.x, 0x05040100u);
         p0[W0STR + W0HIST + lane] = __builtin_amdgcn_perm(v.y, v.x, 0x07060302u);
         wave_sync();
@@ -316,9 +326,16 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
         wdescend<G, 0, false>(lds, lane, 0, cnt, oc);
         hist0(cnt);
     };
+    auto single = [&](size_t pos, int cnt, bool store) {
+        const int m = 2 * lane;
+        uint2_t v = (uint2_t){0u, 0u};
+        if (m < cnt) v.x = SDRHIP_STREAM_LOAD(in + pos + m);
+        if (m + 1 < cnt) v.y = SDRHIP_STREAM_LOAD(in + pos + m + 1);
+        single_v(v, cnt, store);
+    };
 
     size_t pos = seg_start;
-    if (seg != 0) single(seg_start - WWARM, WWARM, false); // histories of the slice from the 44 inputs in front of it, stores suppressed
+    if (seg != 0) single_v(wv, WWARM, false); // histories of the slice from the 44 inputs in front of it, stores suppressed
     oc.store = true;
     for (int p = 0; p < npairs; ++p) {
         // the pair's 256 samples: lane t holds samples 4t .. 4t+3 -> packed dwords 2t, 2t+1 of both planes

@@ -122,7 +122,9 @@ def test_four_wave_workgroups_ragged_tail(ctx, oracle, path):
     path(128)
     S, n = 3, 128 * 1369 + 5
     x = np.stack([signals.noise(n, 900 + s) for s in range(S)])
-    xd = torch.from_numpy(x).cuda()
+    xp = torch.zeros((S, n + 3, 2), dtype=torch.int16, device="cuda")  # (device rows: strides are multiples of four samples)
+    xp[:, :n] = torch.from_numpy(x).cuda()
+    xd = xp[:, :n]
     for log2 in (2, 5):
         u = sd.Interpolators(ctx, S)
         y = u.interpolate(log2, xd)
