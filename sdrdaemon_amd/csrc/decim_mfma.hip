@@ -468,15 +468,22 @@ template <int L, bool PACK16> __global__ __launch_bounds__(mf_block_threads(L), 
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
     const int bx = blockIdx.x;
     if (bx >= nmf) {
-        const int lx = bx - nmf;
-        const int stream = lx / a.mf_npieces, piece = lx - stream * a.mf_npieces;
-        if (piece == 0) {
-            decim_piece<L, 2, PACK16>(a, lds, stream, 0, a.mf_head, true, false, piece, a.mf_npieces);
-        } else {
-            const size_t s0 = a.mf_tail_start + (size_t)(piece - 1) * a.mf_tail_seg;
-            size_t s1 = s0 + a.mf_tail_seg;
-            if (s1 > a.n_used || piece == a.mf_npieces - 1) s1 = a.n_used;
-            decim_piece<L, 2, PACK16>(a, lds, stream, s0, s1, false, piece == a.mf_npieces - 1, piece, a.mf_npieces);
+        // mf_piece_wgs workgroups share the pieces.  With the LDS-DMA ring every workgroup of this kernel owns a whole CU's LDS, so a
+        // piece workgroup never sits beside a matrix-core one: only as many of them as the planner left CUs free start with the
+        // launch, and the others ran AFTER the matrix-core waves (tools/experiments_r04/k1m_stamps.py: 16 of 24 started at 272-289 us
+        // of a 278-us matrix part and ended at 293-310).  So there are as many piece workgroups as free CUs, each takes several pieces.
+        const int nitems = a.nstreams * a.mf_npieces, step = a.mf_piece_wgs > 0 ? a.mf_piece_wgs : nitems;
+        for (int lx = bx - nmf; lx < nitems; lx += step) {
+            const int stream = lx / a.mf_npieces, piece = lx - stream * a.mf_npieces;
+            if (piece == 0) {
+                decim_piece<L, 2, PACK16>(a, lds, stream, 0, a.mf_head, true, false, piece, a.mf_npieces);
+            } else {
+                const size_t s0 = a.mf_tail_start + (size_t)(piece - 1) * a.mf_tail_seg;
+                size_t s1 = s0 + a.mf_tail_seg;
+                if (s1 > a.n_used || piece == a.mf_npieces - 1) s1 = a.n_used;
+                decim_piece<L, 2, PACK16>(a, lds, stream, s0, s1, false, piece == a.mf_npieces - 1, piece, a.mf_npieces);
+            }
+            __syncthreads(); // (the next piece reuses the stage buffers)
         }
         return;
     }
@@ -567,7 +574,7 @@ template <int L> hipError_t launch_fused(bool pack16, const DecimArgs &a, const 
 
 template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream_t stream)
 {
-    const int nleg = a.nstreams * a.mf_npieces;
+    const int nleg = a.mf_piece_wgs > 0 ? a.mf_piece_wgs : a.nstreams * a.mf_npieces;
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
     const dim3 grid(nleg + nmf), block(mf_block_threads(L));
     if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true>), grid, block, 0, stream, a);
@@ -652,6 +659,13 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
     a->mf_tail_start = tail_start;
     a->mf_tail_seg = seg;
     a->mf_npieces = 1 + (int)ntail;
+    {
+        // piece workgroups (see decim_mfma_kernel): all of them, unless the matrix-core workgroups own their CUs (LDS-DMA ring) and
+        // leave some free -- then one per free CU
+        const int items = nstreams * a->mf_npieces, nmf = (int)(((size_t)nstreams * wps + 3) / 4);
+        a->mf_piece_wgs = items;
+        if (mf_dma_applies(log2decim) && n_cu > nmf && n_cu - nmf < items) a->mf_piece_wgs = n_cu - nmf;
+    }
     return true;
 }
 
