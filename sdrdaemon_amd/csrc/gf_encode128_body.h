@@ -59,11 +59,72 @@ template <int LEAF, int P> __device__ __forceinline__ void leaf_issue(LeafRegs &
 // kernel blocks (the two 16-row tiles of a row pair) see the same z sums, so the tree's XORs on the z side
 // and the three selector words of every leaf are formed once and used twice.  la16 / la4, lb16 / lb4 = LDS
 // byte addresses of the leaf tables of the two blocks.  The caller issues leaf 0 (leaf_issue<0, 0>) in front of the walk.
+// the three selector words of a data dword (kmul): bitwise functions of z, so sel(z ^ w) = sel(z) ^ sel(w)
+struct Sel3 { unsigned a, b, c; };
+__device__ __forceinline__ Sel3 sel_of(unsigned z)
+{
+    return Sel3{z & 0x07070707u, (z >> 3) & 0x07070707u, (z >> 6) & 0x03030303u};
+}
+__device__ __forceinline__ Sel3 sel_xor(const Sel3 &x, const Sel3 &y) { return Sel3{x.a ^ y.a, x.b ^ y.b, x.c ^ y.c}; }
+
+// one leaf with its selector words given: ya[YI] ^= ta * z, yb[YI] ^= tb * z (tables of leaf LEAF, fetched one leaf ahead)
+template <int LEAF, int YI>
+__device__ __forceinline__ void leaf_apply(Sel3 &s, unsigned (&ya)[KN], unsigned (&yb)[KN], unsigned la16, unsigned la4, unsigned lb16,
+                                           unsigned lb4, LeafRegs &R)
+{
+    constexpr int P = LEAF & 1;
+    // (the selector words are tied to the statement: whatever forms them -- an XOR of two earlier leaves' words -- stays here)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.ta[P]), "+v"(R.tca[P]), "+v"(R.tb[P]), "+v"(R.tcb[P]), "+v"(s.a), "+v"(s.b), "+v"(s.c)::"memory");
+    if constexpr (LEAF + 1 < KLEAVES) leaf_issue<LEAF + 1, P ^ 1>(R, la16, la4, lb16, lb4);
+    const uint4_t ta = R.ta[P], tb = R.tb[P];
+    const unsigned tca = R.tca[P], tcb = R.tcb[P];
+    ya[YI] ^= __builtin_amdgcn_perm(ta.y, ta.x, s.a) ^ __builtin_amdgcn_perm(ta.w, ta.z, s.b) ^ __builtin_amdgcn_perm(0u, tca, s.c);
+    yb[YI] ^= __builtin_amdgcn_perm(tb.y, tb.x, s.a) ^ __builtin_amdgcn_perm(tb.w, tb.z, s.b) ^ __builtin_amdgcn_perm(0u, tcb, s.c);
+    asm volatile("" : "+v"(ya[YI]), "+v"(yb[YI]));
+}
+
 template <int N, int ZO, int YO, int LEAF0>
 __device__ __forceinline__ void acc_conv2(unsigned (&v)[2 * KN - 1], unsigned (&ya)[KN], unsigned (&yb)[KN], unsigned la16, unsigned la4,
                                           unsigned lb16, unsigned lb4, LeafRegs &R)
 {
-    if constexpr (N == 1) {
+#ifndef KARA_SEL4
+#define KARA_SEL4 1
+#endif
+    if constexpr (N == 4 && KARA_SEL4) {
+        // The lowest two levels of the tree in the SELECTOR domain (round 4): the nine leaves of a 4-point node need the selector
+        // words of z0..z3 and of five XOR combinations of them; formed from the four inputs' words (4 x 5 + 5 x 3 instructions)
+        // instead of from nine z values (5 XORs + 9 x 5): -15 per node, -135 per walk.  Same leaf order, same y-side XORs as the
+        // recursion below.
+#define KY(i, j) do { ya[YO + (i)] ^= ya[YO + (j)]; yb[YO + (i)] ^= yb[YO + (j)]; } while (0)
+        KY(2, 0); KY(3, 1);
+        unsigned z0 = v[ZO], z1 = v[ZO + 1];
+        asm volatile("" : "+v"(z0), "+v"(z1)); // (selector words are formed here, not where v[] is produced)
+        Sel3 s0 = sel_of(z0), s1 = sel_of(z1);
+        KY(1, 0);
+        leaf_apply<LEAF0, YO>(s0, ya, yb, la16, la4, lb16, lb4, R);
+        leaf_apply<LEAF0 + 1, YO>(s1, ya, yb, la16, la4, lb16, lb4, R);
+        { Sel3 t = sel_xor(s0, s1); leaf_apply<LEAF0 + 2, YO + 1>(t, ya, yb, la16, la4, lb16, lb4, R); }
+        KY(1, 0);
+        unsigned z2 = v[ZO + 2], z3 = v[ZO + 3];
+        asm volatile("" : "+v"(z2), "+v"(z3));
+        Sel3 s2 = sel_of(z2), s3 = sel_of(z3);
+        s0 = sel_xor(s0, s2); s1 = sel_xor(s1, s3); // (the third child's words now: twelve selector registers live, not fifteen)
+        asm volatile("" : "+v"(s0.a), "+v"(s0.b), "+v"(s0.c), "+v"(s1.a), "+v"(s1.b), "+v"(s1.c));
+        KY(1, 0);
+        leaf_apply<LEAF0 + 3, YO>(s2, ya, yb, la16, la4, lb16, lb4, R);
+        leaf_apply<LEAF0 + 4, YO>(s3, ya, yb, la16, la4, lb16, lb4, R);
+        s2 = sel_xor(s2, s3);
+        leaf_apply<LEAF0 + 5, YO + 1>(s2, ya, yb, la16, la4, lb16, lb4, R);
+        KY(1, 0);
+        KY(3, 2);
+        leaf_apply<LEAF0 + 6, YO + 2>(s0, ya, yb, la16, la4, lb16, lb4, R);
+        leaf_apply<LEAF0 + 7, YO + 2>(s1, ya, yb, la16, la4, lb16, lb4, R);
+        s0 = sel_xor(s0, s1);
+        leaf_apply<LEAF0 + 8, YO + 3>(s0, ya, yb, la16, la4, lb16, lb4, R);
+        KY(3, 2);
+        KY(2, 0); KY(3, 1);
+#undef KY
+    } else if constexpr (N == 1) {
         // The 81 table loads of a block have immediate addresses; left to the compiler they are all hoisted to the top
         // (hundreds of VGPRs of tables) and spilled.  asm statements keep them in program order, one leaf ahead.
         constexpr int P = LEAF0 & 1;
