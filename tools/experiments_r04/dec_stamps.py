@@ -44,3 +44,18 @@ print("start of workgroups, us after the first: quartiles", np.percentile((st[:,
 for k, n in enumerate(names):
     print("%-56s mean %7.2f us   p10 %7.2f  p90 %7.2f" % (n, d[:, k].mean() / 1e3, np.percentile(d[:, k], 10) / 1e3, np.percentile(d[:, k], 90) / 1e3))
 print("%-56s mean %7.2f us" % ("whole workgroup", (st[:, 6] - st[:, 0]).mean() * 0.01))
+# residency: workgroups per CU over time
+lib.sdrhip_debug_dec_occupancy.restype = ctypes.c_int
+print("hipOccupancyMaxActiveBlocksPerMultiprocessor(gf_decode128_kernel, 256 threads): %d" % lib.sdrhip_debug_dec_occupancy())
+full = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8)[:2 * Stx * F].astype(np.int64)
+hw = full[:, 7]
+key = ((hw >> 32) & 0xf) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 8) & 0xf)
+cus = np.unique(key)
+print("CUs seen: %d" % len(cus))
+ts = np.arange(0, (st[:, 6].max() - t0), 200)  # every 2 us
+conc = np.array([((st[:, 0] - t0 <= t) & (st[:, 6] - t0 > t)).sum() for t in ts])
+print("resident workgroups chip-wide every 10 us:", [int(c) for c in conc[::5]])
+per_cu_max = [max(((st[key == c, 0] - t0 <= t) & (st[key == c, 6] - t0 > t)).sum() for t in ts[::2]) for c in cus[:64]]
+print("max resident workgroups on a CU (first 64 CUs):", np.bincount(per_cu_max))
+first = np.sort(st[:, 0] - t0) * 0.01
+print("start time of the k-th workgroup, us: k=256 %.1f  512 %.1f  768 %.1f  1024 %.1f  1280 %.1f  1536 %.1f" % tuple(first[[255, 511, 767, 1023, 1279, 1535]]))
