@@ -25,7 +25,7 @@ constexpr int GF_NT = 256;
 __device__ __forceinline__ unsigned kmul(unsigned zval, const uint4_t &t, unsigned tc)
 {
     const unsigned sa = zval & 0x07070707u, sb = (zval >> 3) & 0x07070707u, sc = (zval >> 6) & 0x03030303u;
-    return __builtin_amdgcn_perm(t.y, t.x, sa) ^ __builtin_amdgcn_perm(t.w, t.z, sb) ^ __builtin_amdgcn_perm(0u, tc, sc);
+    return __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_perm(t.y, t.x, sa), __builtin_amdgcn_perm(t.w, t.z, sb), __builtin_amdgcn_perm(0u, tc, sc), 0x96);
 }
 
 __device__ __forceinline__ unsigned lds_addr(const void *p)
@@ -55,10 +55,6 @@ template <int LEAF, int P> __device__ __forceinline__ void leaf_issue(LeafRegs &
                  : "memory");
 }
 
-// ya[YO .. YO+N) ^= ga (*) v[ZO .. ZO+N) and yb[..] ^= gb (*) v[..] in one walk of the Karatsuba tree: the two
-// kernel blocks (the two 16-row tiles of a row pair) see the same z sums, so the tree's XORs on the z side
-// and the three selector words of every leaf are formed once and used twice.  la16 / la4, lb16 / lb4 = LDS
-// byte addresses of the leaf tables of the two blocks.  The caller issues leaf 0 (leaf_issue<0, 0>) in front of the walk.
 // the three selector words of a data dword (kmul): bitwise functions of z, so sel(z ^ w) = sel(z) ^ sel(w)
 struct Sel3 { unsigned a, b, c; };
 __device__ __forceinline__ Sel3 sel_of(unsigned z)
@@ -67,10 +63,10 @@ __device__ __forceinline__ Sel3 sel_of(unsigned z)
 }
 __device__ __forceinline__ Sel3 sel_xor(const Sel3 &x, const Sel3 &y) { return Sel3{x.a ^ y.a, x.b ^ y.b, x.c ^ y.c}; }
 
-// one leaf with its selector words given: ya[YI] ^= ta * z, yb[YI] ^= tb * z (tables of leaf LEAF, fetched one leaf ahead)
-template <int LEAF, int YI>
-__device__ __forceinline__ void leaf_apply(Sel3 &s, unsigned (&ya)[KN], unsigned (&yb)[KN], unsigned la16, unsigned la4, unsigned lb16,
-                                           unsigned lb4, LeafRegs &R)
+// the six v_perm products of one leaf for the two tiles (tables of leaf LEAF, fetched one leaf ahead; the next leaf's go out here)
+struct LeafProd { unsigned a0, a1, a2, b0, b1, b2; };
+template <int LEAF>
+__device__ __forceinline__ LeafProd leaf_products(Sel3 &s, unsigned la16, unsigned la4, unsigned lb16, unsigned lb4, LeafRegs &R)
 {
     constexpr int P = LEAF & 1;
     // (the selector words are tied to the statement: whatever forms them -- an XOR of two earlier leaves' words -- stays here)
@@ -78,66 +74,65 @@ __device__ __forceinline__ void leaf_apply(Sel3 &s, unsigned (&ya)[KN], unsigned
     if constexpr (LEAF + 1 < KLEAVES) leaf_issue<LEAF + 1, P ^ 1>(R, la16, la4, lb16, lb4);
     const uint4_t ta = R.ta[P], tb = R.tb[P];
     const unsigned tca = R.tca[P], tcb = R.tcb[P];
-    ya[YI] ^= __builtin_amdgcn_perm(ta.y, ta.x, s.a) ^ __builtin_amdgcn_perm(ta.w, ta.z, s.b) ^ __builtin_amdgcn_perm(0u, tca, s.c);
-    yb[YI] ^= __builtin_amdgcn_perm(tb.y, tb.x, s.a) ^ __builtin_amdgcn_perm(tb.w, tb.z, s.b) ^ __builtin_amdgcn_perm(0u, tcb, s.c);
-    asm volatile("" : "+v"(ya[YI]), "+v"(yb[YI]));
+    return LeafProd{__builtin_amdgcn_perm(ta.y, ta.x, s.a), __builtin_amdgcn_perm(ta.w, ta.z, s.b), __builtin_amdgcn_perm(0u, tca, s.c),
+                    __builtin_amdgcn_perm(tb.y, tb.x, s.a), __builtin_amdgcn_perm(tb.w, tb.z, s.b), __builtin_amdgcn_perm(0u, tcb, s.c)};
 }
+__device__ __forceinline__ unsigned x3(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); } // a ^ b ^ c: one v_bitop3_b32
 
+// ya[YO .. YO+N) ^= ga (*) v[ZO .. ZO+N) and yb[..] ^= gb (*) v[..] in one walk of the Karatsuba tree: the two
+// kernel blocks (the two 16-row tiles of a row pair) see the same z sums, so the tree's XORs on the z side
+// and the three selector words of every leaf are formed once and used twice.  la16 / la4, lb16 / lb4 = LDS
+// byte addresses of the leaf tables of the two blocks.  The caller issues leaf 0 (leaf_issue<0, 0>) in front of the walk.
+// (The 81 table loads of a block have immediate addresses; left to the compiler they are all hoisted to the top -- hundreds of
+// VGPRs of tables -- and spilled: asm statements keep them in program order, one leaf ahead.)
 template <int N, int ZO, int YO, int LEAF0>
 __device__ __forceinline__ void acc_conv2(unsigned (&v)[2 * KN - 1], unsigned (&ya)[KN], unsigned (&yb)[KN], unsigned la16, unsigned la4,
                                           unsigned lb16, unsigned lb4, LeafRegs &R)
 {
-#ifndef KARA_SEL4
-#define KARA_SEL4 1
-#endif
-    if constexpr (N == 4 && KARA_SEL4) {
-        // The lowest two levels of the tree in the SELECTOR domain (round 4): the nine leaves of a 4-point node need the selector
-        // words of z0..z3 and of five XOR combinations of them; formed from the four inputs' words (4 x 5 + 5 x 3 instructions)
-        // instead of from nine z values (5 XORs + 9 x 5): -15 per node, -135 per walk.  Same leaf order, same y-side XORs as the
-        // recursion below.
-#define KY(i, j) do { ya[YO + (i)] ^= ya[YO + (j)]; yb[YO + (i)] ^= yb[YO + (j)]; } while (0)
-        KY(2, 0); KY(3, 1);
+    if constexpr (N == 4) {
+        // The lowest two levels of the tree, hand-scheduled (round 4):
+        //  * SELECTOR domain: the nine leaves of a 4-point node need the selector words of z0..z3 and of five XOR combinations of
+        //    them; formed from the four inputs' words (4 x 5 + 5 x 3 instructions) instead of from nine z values (5 XORs + 9 x 5);
+        //  * the y side in 3-input XORs (v_bitop3_b32): written out, the node is y0 ^= P0 ^ P1 ^ P3 ^ P4, y1 ^= y0o ^ P2 ^ P5 ^ y0',
+        //    y2 ^= y0o ^ P6 ^ P7 ^ y0', y3 ^= y1o ^ y2 ^ y0o ^ P8 ^ y2b ^ y1' (Pk = the three v_perm products of leaf k; o = on
+        //    entry, ' = final; the recursion's post-XOR of the first child and pre-XOR of the second cancel): 20 instructions per
+        //    tile instead of 37 two-input XORs.  Measured: the encoder 0.0611 -> 0.0583 (selectors) -> 0.0518 ms per 1040 frames.
+        // Same leaf order as the recursion below (the table layout does not change).
+        unsigned &a0 = ya[YO], &a1 = ya[YO + 1], &a2 = ya[YO + 2], &a3 = ya[YO + 3];
+        unsigned &b0 = yb[YO], &b1 = yb[YO + 1], &b2 = yb[YO + 2], &b3 = yb[YO + 3];
+        a2 ^= a0; b2 ^= b0;                        // y2a = y2 ^ y0o
+        a3 = x3(a3, a1, a2); b3 = x3(b3, b1, b2);  // y3b = y3 ^ y1o ^ y2a
+        a1 ^= a0; b1 ^= b0;                        // y1 ^ y0o
         unsigned z0 = v[ZO], z1 = v[ZO + 1];
         asm volatile("" : "+v"(z0), "+v"(z1)); // (selector words are formed here, not where v[] is produced)
         Sel3 s0 = sel_of(z0), s1 = sel_of(z1);
-        KY(1, 0);
-        leaf_apply<LEAF0, YO>(s0, ya, yb, la16, la4, lb16, lb4, R);
-        leaf_apply<LEAF0 + 1, YO>(s1, ya, yb, la16, la4, lb16, lb4, R);
-        { Sel3 t = sel_xor(s0, s1); leaf_apply<LEAF0 + 2, YO + 1>(t, ya, yb, la16, la4, lb16, lb4, R); }
-        KY(1, 0);
+        unsigned pa, pb; // a product waiting for a partner
+        { const LeafProd q = leaf_products<LEAF0>(s0, la16, la4, lb16, lb4, R); a0 = x3(a0, q.a0, q.a1); b0 = x3(b0, q.b0, q.b1); pa = q.a2; pb = q.b2; }
+        asm volatile("" : "+v"(a0), "+v"(b0), "+v"(pa), "+v"(pb)); // accumulate now: the compiler otherwise parks the products of many leaves
+        { const LeafProd q = leaf_products<LEAF0 + 1>(s1, la16, la4, lb16, lb4, R); a0 = x3(x3(a0, pa, q.a0), q.a1, q.a2); b0 = x3(x3(b0, pb, q.b0), q.b1, q.b2); }
+        asm volatile("" : "+v"(a0), "+v"(b0));
+        { Sel3 t = sel_xor(s0, s1); const LeafProd q = leaf_products<LEAF0 + 2>(t, la16, la4, lb16, lb4, R); a1 = x3(a1, q.a0, q.a1) ^ q.a2; b1 = x3(b1, q.b0, q.b1) ^ q.b2; }
+        asm volatile("" : "+v"(a1), "+v"(b1));
         unsigned z2 = v[ZO + 2], z3 = v[ZO + 3];
         asm volatile("" : "+v"(z2), "+v"(z3));
         Sel3 s2 = sel_of(z2), s3 = sel_of(z3);
         s0 = sel_xor(s0, s2); s1 = sel_xor(s1, s3); // (the third child's words now: twelve selector registers live, not fifteen)
         asm volatile("" : "+v"(s0.a), "+v"(s0.b), "+v"(s0.c), "+v"(s1.a), "+v"(s1.b), "+v"(s1.c));
-        KY(1, 0);
-        leaf_apply<LEAF0 + 3, YO>(s2, ya, yb, la16, la4, lb16, lb4, R);
-        leaf_apply<LEAF0 + 4, YO>(s3, ya, yb, la16, la4, lb16, lb4, R);
+        { const LeafProd q = leaf_products<LEAF0 + 3>(s2, la16, la4, lb16, lb4, R); a0 = x3(a0, q.a0, q.a1); b0 = x3(b0, q.b0, q.b1); pa = q.a2; pb = q.b2; }
+        asm volatile("" : "+v"(a0), "+v"(b0), "+v"(pa), "+v"(pb));
+        { const LeafProd q = leaf_products<LEAF0 + 4>(s3, la16, la4, lb16, lb4, R); a0 = x3(x3(a0, pa, q.a0), q.a1, q.a2); b0 = x3(x3(b0, pb, q.b0), q.b1, q.b2); }
+        asm volatile("" : "+v"(a0), "+v"(b0)); // y0'
         s2 = sel_xor(s2, s3);
-        leaf_apply<LEAF0 + 5, YO + 1>(s2, ya, yb, la16, la4, lb16, lb4, R);
-        KY(1, 0);
-        KY(3, 2);
-        leaf_apply<LEAF0 + 6, YO + 2>(s0, ya, yb, la16, la4, lb16, lb4, R);
-        leaf_apply<LEAF0 + 7, YO + 2>(s1, ya, yb, la16, la4, lb16, lb4, R);
+        { const LeafProd q = leaf_products<LEAF0 + 5>(s2, la16, la4, lb16, lb4, R); a1 = x3(x3(a1, q.a0, q.a1), q.a2, a0); b1 = x3(x3(b1, q.b0, q.b1), q.b2, b0); }
+        asm volatile("" : "+v"(a1), "+v"(b1)); // y1'
+        { const LeafProd q = leaf_products<LEAF0 + 6>(s0, la16, la4, lb16, lb4, R); a2 = x3(a2, q.a0, q.a1); b2 = x3(b2, q.b0, q.b1); pa = q.a2; pb = q.b2; }
+        asm volatile("" : "+v"(a2), "+v"(b2), "+v"(pa), "+v"(pb));
+        { const LeafProd q = leaf_products<LEAF0 + 7>(s1, la16, la4, lb16, lb4, R); a2 = x3(x3(a2, pa, q.a0), q.a1, q.a2); b2 = x3(x3(b2, pb, q.b0), q.b1, q.b2); }
+        asm volatile("" : "+v"(a2), "+v"(b2)); // y2b
         s0 = sel_xor(s0, s1);
-        leaf_apply<LEAF0 + 8, YO + 3>(s0, ya, yb, la16, la4, lb16, lb4, R);
-        KY(3, 2);
-        KY(2, 0); KY(3, 1);
-#undef KY
-    } else if constexpr (N == 1) {
-        // The 81 table loads of a block have immediate addresses; left to the compiler they are all hoisted to the top
-        // (hundreds of VGPRs of tables) and spilled.  asm statements keep them in program order, one leaf ahead.
-        constexpr int P = LEAF0 & 1;
-        unsigned z = v[ZO]; // tied to the statement ("+v") so that its three selector dwords are formed here,
-                            // not when v[ZO] is produced (that alone tripled the live registers)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.ta[P]), "+v"(R.tca[P]), "+v"(R.tb[P]), "+v"(R.tcb[P]), "+v"(z)::"memory"); // this leaf's tables have landed
-        if constexpr (LEAF0 + 1 < KLEAVES) leaf_issue<LEAF0 + 1, P ^ 1>(R, la16, la4, lb16, lb4);
-        const uint4_t ta = R.ta[P], tb = R.tb[P];
-        const unsigned tca = R.tca[P], tcb = R.tcb[P];
-        const unsigned sa = z & 0x07070707u, sb = (z >> 3) & 0x07070707u, sc = (z >> 6) & 0x03030303u;
-        ya[YO] ^= __builtin_amdgcn_perm(ta.y, ta.x, sa) ^ __builtin_amdgcn_perm(ta.w, ta.z, sb) ^ __builtin_amdgcn_perm(0u, tca, sc);
-        yb[YO] ^= __builtin_amdgcn_perm(tb.y, tb.x, sa) ^ __builtin_amdgcn_perm(tb.w, tb.z, sb) ^ __builtin_amdgcn_perm(0u, tcb, sc);
-        asm volatile("" : "+v"(ya[YO]), "+v"(yb[YO])); // accumulate now: the compiler otherwise parks the six products of many leaves
+        { const LeafProd q = leaf_products<LEAF0 + 8>(s0, la16, la4, lb16, lb4, R); a3 = x3(x3(a3, q.a0, q.a1), q.a2, a2) ^ a1; b3 = x3(x3(b3, q.b0, q.b1), q.b2, b2) ^ b1; }
+        a2 ^= a0; b2 ^= b0; // y2' = y2b ^ y0'
+        asm volatile("" : "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3));
     } else {
         constexpr int H = N / 2, L3 = pow3(H);
 #pragma unroll

@@ -47,7 +47,7 @@ __device__ __forceinline__ unsigned mulc(const Sel &s, const uint4_t &t, unsigne
     unsigned pa = __builtin_amdgcn_perm(t.y, t.x, s.a);
     unsigned pb = __builtin_amdgcn_perm(t.w, t.z, s.b);
     unsigned pc = __builtin_amdgcn_perm(0u, tc, s.c);
-    return pa ^ pb ^ pc;
+    return __builtin_amdgcn_bitop3_b32(pa, pb, pc, 0x96); // pa ^ pb ^ pc in one v_bitop3_b32 (hipcc emits two v_xor)
 }
 
 __device__ __forceinline__ uint4_t load_slab(const uint8_t *p, int l)
