@@ -259,7 +259,8 @@ def extra_configs(ctx, dev, x, kind):
                           "decimator's launch (rx_fused_kernel)" % S,
                 "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
                 "roofline": roof(BYTES_CONFIG3 * S * n, per[K_DECIMATE], "rx_fused_kernel<4,true> (decimator + encoder of the previous call: "
-                                                                          "config-3 algorithmic bytes, 4.317 B per sample)")})
+                                                                          "config-3 algorithmic bytes, 4.317 B per sample)",
+                                 pmc_traffic(float(S) * n, "rx_fused_kernel<4,true>"))})
     del rxp
     # configs[2] literally: ONE stream (2^27 samples per step) through the fused Rx pipe
     n1 = 1 << 27

@@ -32,7 +32,7 @@ def main():
             print("counters_collection columns:", ccols, e)
             continue
         for n in sorted(set(r[0] for r in pm)):
-            if "decim_kernel" in n or "decim_mfma" in n or "frame_pack" in n or "gf_" in n or "interp_" in n or os.environ.get("ROCPD_ALL_KERNELS"):
+            if "decim_kernel" in n or "decim_mfma" in n or "rx_fused" in n or "frame_pack" in n or "gf_" in n or "interp_" in n or os.environ.get("ROCPD_ALL_KERNELS"):
                 print("  PMC", short(n), "vgpr", [r[4] for r in pm if r[0] == n][0], "lds", [r[5] for r in pm if r[0] == n][0])
                 for r in pm:
                     if r[0] == n:
