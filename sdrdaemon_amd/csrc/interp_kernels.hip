@@ -33,7 +33,7 @@ template <int L> __global__ __launch_bounds__(NT) void interp_kernel(InterpArgs 
     interp_segment<L>(a, blockIdx.x, blockIdx.y, lds);
 }
 
-// K5w: one time slice of one stream per wave, no barrier (interp_wave.h)
+// K5w: one time slice of one stream per wave, no barrier (interp_wave.h).
 // WPW waves per workgroup, each on a segment of its own (no barrier, no shared data: a workgroup is only a way of starting WPW
 // waves at the same moment, which puts their clusters of input loads at the same moment -- see interp_wave_segment; measured
 // 6 % on interpolate32, 0..1 % on the others, tools/experiments_r04 batch 20).  Launches too small to fill the chip with
@@ -80,8 +80,8 @@ void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_s
 // its start), an even number of them (the input comes back a PAIR of blocks at a time; an odd rest runs the guarded path)
 void plan_interpolate_wave(int log2interp, size_t n_in, int nstreams, int n_cu, size_t seg_override, int *nsub_per_seg, int *nseg)
 {
-    (void)nstreams; (void)n_cu;
-    const size_t maxper = 2 * (size_t)wpairs(log2interp);
+    (void)log2interp; (void)nstreams; (void)n_cu;
+    const size_t maxper = 2 * (size_t)WPAIRS;
     size_t nsub = (n_in + WB - 1) / WB;
     if (nsub == 0) nsub = 1;
     size_t per = seg_override ? (seg_override + WB - 1) / WB : maxper;

@@ -27,7 +27,6 @@ constexpr int WSTR = HIST + WCAP; // 288 dwords = 72 sixteen-byte slots = 8 mod 
 // every ratio: the short cascades (interpolate4 / 8: 56-64 VGPRs, four times / twice the input per output) were tried with 4, 6,
 // 12 and 16 -- longer segments cost a wave per SIMD and run 4-10 % slower, shorter ones change nothing (experiments_r04 batch 23)
 constexpr int WPAIRS = 8;
-__host__ __device__ constexpr int wpairs(int) { return WPAIRS; }
 constexpr int WG = 2;            // blocks staged at a time: one dwordx4 load per lane covers a PAIR of blocks (256 samples)
 constexpr int W0HIST = 16;       // packed stage-0 plane: 16 dwords (32 entries) of history + WG x 64 fresh
 constexpr int W0STR = 32 + 64 * WG; // ... padded to 16 mod 32 eight-byte slots: the I / Q lanes of a ds_read_b64 group hit distinct banks
