@@ -265,7 +265,7 @@ __device__ __forceinline__ void gf_encode128_wg(const Enc128Args &a, int bx, uns
                 for (int i = 0; i < KN; ++i) v[i] = 0u;
             }
 #pragma unroll
-            for (int i = 0; i < KN; ++i) p ^= v[i];
+            for (int i = 0; i < KN; i += 2) p = x3(p, v[i], v[i + 1]);
             const int b0 = (2 * tp) ^ cb, b1 = (2 * tp + 1) ^ cb;
             conv_block2(v, y0, y1, lds_addr(lt16 + b0 * KLEAVES), lds_addr(lt4 + b0 * KLEAVES), lds_addr(lt16 + b1 * KLEAVES), lds_addr(lt4 + b1 * KLEAVES));
         }

@@ -572,7 +572,7 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
             }
             if (N == 0) continue; // (copy only)
 #pragma unroll
-            for (int i = 0; i < KN; ++i) p ^= v[i];
+            for (int i = 0; i < KN; i += 2) p = x3(p, v[i], v[i + 1]);
             if (pl->m1) continue; // (parity only)
             const int t0 = (2 * tp) ^ cb, t1 = (2 * tp + 1) ^ cb;
             conv_block2(v, y0, y1, lds_addr(lt16 + t0 * KLEAVES), lds_addr(lt4 + t0 * KLEAVES), lds_addr(lt16 + t1 * KLEAVES), lds_addr(lt4 + t1 * KLEAVES));
@@ -648,9 +648,21 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
             syn_next[k] = syn[i][lane];
             mc_next[k] = *reinterpret_cast<const uint2_t *>(&pl->minv[i * DEC128_MAXN + w * 8]);
         }
+        // two syndromes at a time: their two products per row go into the accumulator with ONE 3-input XOR
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            if (i0 + k < N) {
+        for (int k = 0; k < CH; k += 2) {
+            if (i0 + k + 1 < N) {
+                const Sel sl0 = make_sel(sy[k]), sl1 = make_sel(sy[k + 1]);
+#pragma unroll
+                for (int u = 0; u < DEC128_MAXN / 4; ++u) {
+                    if (u < nmine) {
+                        const unsigned m0 = ((u < 4 ? mc[k].x : mc[k].y) >> (8 * (u & 3))) & 0xffu;
+                        const unsigned m1 = ((u < 4 ? mc[k + 1].x : mc[k + 1].y) >> (8 * (u & 3))) & 0xffu;
+                        acc[u] = __builtin_amdgcn_bitop3_b32(acc[u], mulc(sl0, *reinterpret_cast<const uint4_t *>(&tab[m0 * 8]), tab[m0 * 8 + 4]),
+                                                             mulc(sl1, *reinterpret_cast<const uint4_t *>(&tab[m1 * 8]), tab[m1 * 8 + 4]), 0x96);
+                    }
+                }
+            } else if (i0 + k < N) {
                 const Sel sl = make_sel(sy[k]);
 #pragma unroll
                 for (int u = 0; u < DEC128_MAXN / 4; ++u) {
