@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of K5w's waves (interpolate16, 8 x 2^21 inputs) from s_memrealtime stamps (100 MHz) written by lane 0 of every wave:
+"""Timeline of K5w's waves (8 x 2^21 inputs = 8192 waves; interpolate16 by default) from s_memrealtime stamps (100 MHz) written by lane 0 of every wave:
 variant library built with -DW_STAMPS (tools/experiments_r04/wave_stamps.patch + wave_stamps_kernels.patch).
 usage: SDRHIP_LIB_PATH=tools/experiments_r04/lib/libsdrhip_wstamps.so python tools/experiments_r04/wave_stamps.py [log2interp]"""
 import ctypes
@@ -19,8 +19,8 @@ L = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ctx = sd.Context(0)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
-S, n_out = 8, 1 << 25
-n = n_out >> L
+S, n = 8, 1 << 21  # 8192 waves (the stamp buffer's size) whatever the ratio
+n_out = n << L
 x = torch.randint(-32768, 32768, (S, n, 2), generator=g, device=dev, dtype=torch.int16)
 out = torch.empty((S, n_out, 2), dtype=torch.int16, device=dev)
 ctx.set_option("interp_path", "wave")
