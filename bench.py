@@ -196,6 +196,7 @@ def timed_steps(ctx, fn, classes, steps=40, preroll_s=0.15):
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
+    ctx.set_option("ktime_stride", 4)  # (every 4th launch of a class carries the event pair, see main())
     ctx.kernel_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -208,6 +209,7 @@ def timed_steps(ctx, fn, classes, steps=40, preroll_s=0.15):
         ms, cnt = ctx.kernel_timing_read(c)
         per[c] = ms / max(cnt, 1)
     ctx.kernel_timing(False)
+    ctx.set_option("ktime_stride", 1)
     return wall, per
 
 
@@ -431,6 +433,8 @@ def main():
     ap.add_argument("--preroll-seconds", type=float, default=0.25,
                     help="untimed run-in of the same step before the W warm-up steps (the GPU's clocks ramp over the first "
                          "~60 ms of load: with a small W the timed steps would measure that ramp)")
+    ap.add_argument("--timer-stride", type=int, default=4,
+                    help="the HIP-event timers of the roofline kernel bracket every N-th step of the timed region (default 4)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: leave the per-kernel HIP events out of the timed region (roofline fields become null)")
     ap.add_argument("--force-dist", action="store_true",
@@ -508,6 +512,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    # kernel-class timers (HIP events on the library's stream) over the timed region: every 4th step's launches -- an event pair
+    # costs the stream ~2.5 us, four of them per step took 3 % off the step (tools/bench_rx_modes.py times the same step without)
+    ctx.set_option("ktime_stride", args.timer_stride)
     ctx.kernel_timing(not args.no_kernel_timing)
     if dist is not None:
         dist.barrier()
@@ -523,6 +530,7 @@ def main():
     dec_ms, dec_n = ctx.kernel_timing_read(K_DECIMATE)
     fec_ms, fec_n = ctx.kernel_timing_read(K_FEC_ENCODE)
     ctx.kernel_timing(False)
+    ctx.set_option("ktime_stride", 1)
     plan = rx.last_plan()
     kname = decim_kernel_name(plan)
     verified = None if args.no_verify else verify_step(ctx, x, ids, args.input)
@@ -559,7 +567,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(per_launch_samples, kname),
                          "traffic_source": "profiles/traffic.json (PMC passes of tools/prof.sh on this command, committed; not measured by this run)",
-                         "kernel": kname, "launches": dec_n, "avg_launch_ms": round(avg_ms, 4), "plan": plan,
+                         "kernel": kname, "launches": dec_n, "timer_stride": args.timer_stride, "avg_launch_ms": round(avg_ms, 4), "plan": plan,
                          "algorithmic_bytes_per_launch": BYTES_DECIM * per_launch_samples,
                          "pipe_gbps_config3": round(BYTES_CONFIG3 * value * 1e6 / 1e9 / world, 1),
                          "fec_encode_avg_launch_ms": round(fec_ms / max(fec_n, 1), 4), "fec_encode_launches": fec_n},

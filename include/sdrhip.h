@@ -95,7 +95,9 @@ int sdrhip_ctx_timing_begin(sdrhip_ctx *ctx);
 int sdrhip_ctx_timing_end(sdrhip_ctx *ctx, float *elapsed_ms);
 /* Per-kernel-class timing: while enabled, every launch of the class is bracketed by
  * hipEvents on the context's stream.  _read synchronises, returns the summed duration and
- * the number of launches since the last read, and clears the log.  Classes: */
+ * the number of launches since the last read, and clears the log.  An event pair costs the
+ * stream ~2.5 us: sdrhip_ctx_set_option("ktime_stride", "N") brackets only every N-th launch of
+ * a class (default 1; bench.py samples every 4th step of its timed region).  Classes: */
 #define SDRHIP_K_DECIMATE 0    /* half-band decimator cascade kernel */
 #define SDRHIP_K_INTERPOLATE 1 /* half-band interpolator cascade kernel */
 #define SDRHIP_K_FEC_ENCODE 2  /* GF(256) matrix apply, encoder rows */

@@ -205,6 +205,7 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
         else return fail(SDRHIP_EINVAL, "ctx_set_option: dec_path must be syndrome or dense");
     } else if (k == "dec_max_rows" && isnum && num >= 1 && num <= 128) c->opt.dec_max_rows = (int)num;
     else if (k == "dec_strict" && isnum && num <= 1) c->opt.dec_strict = (int)num;
+    else if (k == "ktime_stride" && isnum && num >= 1 && num <= 1024) c->ktime_stride = (int)num;
     else return fail(SDRHIP_EINVAL, "ctx_set_option: unknown key or malformed value: %s=%s", key, value);
     return SDRHIP_OK;
 }
@@ -273,6 +274,7 @@ extern "C" int sdrhip_ctx_kernel_timing(sdrhip_ctx *c, int enable)
     if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
     sdrhip::CtxLock lock_(c);
     c->ktime_on = enable != 0;
+    for (int i = 0; i < 4; ++i) c->ktime_seen[i] = 0;
     if (!enable) drop_kernel_events(c); // pairs nobody read
     return SDRHIP_OK;
 }

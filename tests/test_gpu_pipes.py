@@ -517,3 +517,27 @@ def test_rx_submit_and_collect_from_two_threads(ctx, oracle):
     assert not t.is_alive() and not errors, errors
     got = np.concatenate(got, axis=0)
     assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
+def test_kernel_class_timers_sample_every_nth_launch(ctx):
+    """`ktime_stride` = N: the HIP-event pair of the kernel-class timers goes around every N-th launch of a class (what bench.py
+    uses over its timed region); the count restarts when timing is switched on, so the first launch is always timed"""
+    import sdrdaemon_amd as sd
+    from sdrdaemon_amd.engine import K_INTERPOLATE
+
+    x = signals.noise(4096, 3)
+    u = sd.Interpolators(ctx, 1)
+    try:
+        for stride, launches, expect in ((1, 6, 6), (4, 9, 3), (4, 1, 1), (3, 3, 1)):
+            ctx.set_option("ktime_stride", stride)
+            ctx.kernel_timing(True)
+            for _ in range(launches):
+                u.interpolate(4, x)
+            ms, cnt = ctx.kernel_timing_read(K_INTERPOLATE)
+            ctx.kernel_timing(False)
+            assert cnt == expect and ms > 0.0, (stride, launches, cnt, ms)
+        with pytest.raises(sd.SdrHipError):
+            ctx.set_option("ktime_stride", 0)
+    finally:
+        ctx.set_option("ktime_stride", 1)
+        ctx.kernel_timing(False)
