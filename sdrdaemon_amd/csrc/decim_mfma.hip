@@ -468,12 +468,16 @@ template <int L, bool PACK16> __global__ __launch_bounds__(mf_block_threads(L), 
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
     const int bx = blockIdx.x;
     if (bx >= nmf) {
-        // mf_piece_wgs workgroups share the pieces.  With the LDS-DMA ring every workgroup of this kernel owns a whole CU's LDS, so a
-        // piece workgroup never sits beside a matrix-core one: only as many of them as the planner left CUs free start with the
-        // launch, and the others ran AFTER the matrix-core waves (tools/experiments_r04/k1m_stamps.py: 16 of 24 started at 272-289 us
-        // of a 278-us matrix part and ended at 293-310).  So there are as many piece workgroups as free CUs, each takes several pieces.
-        const int nitems = a.nstreams * a.mf_npieces, step = a.mf_piece_wgs > 0 ? a.mf_piece_wgs : nitems;
-        for (int lx = bx - nmf; lx < nitems; lx += step) {
+        // With the LDS-DMA ring every workgroup of this kernel owns a whole CU's LDS, so a piece workgroup never sits beside a
+        // matrix-core one: only as many of them as the planner left CUs free start with the launch, the others run AFTER the
+        // matrix-core waves (tools/experiments_r04/k1m_stamps.py: 16 of 24 started at 272-289 us of a 278-us matrix part).  So the
+        // first mf_piece_early piece workgroups (one per free CU) take mf_piece_share pieces each -- as many as fit beside the matrix
+        // part -- and only what is left after that goes to workgroups of a single piece behind it.
+        const int nitems = a.nstreams * a.mf_npieces, j = bx - nmf, nearly = a.mf_piece_early * a.mf_piece_share;
+        const int nmine = j < a.mf_piece_early ? a.mf_piece_share : 1;
+        for (int k = 0; k < nmine; ++k) {
+            const int lx = j < a.mf_piece_early ? j + k * a.mf_piece_early : nearly + (j - a.mf_piece_early);
+            if (lx >= nitems || (j < a.mf_piece_early && lx >= nearly)) break; // (workgroup-uniform)
             const int stream = lx / a.mf_npieces, piece = lx - stream * a.mf_npieces;
             if (piece == 0) {
                 decim_piece<L, 2, PACK16>(a, lds, stream, 0, a.mf_head, true, false, piece, a.mf_npieces);
@@ -660,11 +664,21 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
     a->mf_tail_seg = seg;
     a->mf_npieces = 1 + (int)ntail;
     {
-        // piece workgroups (see decim_mfma_kernel): all of them, unless the matrix-core workgroups own their CUs (LDS-DMA ring) and
-        // leave some free -- then one per free CU
+        // piece workgroups (see decim_mfma_kernel): one piece each, unless the matrix-core workgroups own their CUs (LDS-DMA ring) and
+        // leave some free: then one EARLY workgroup per free CU with as many pieces as fit beside the matrix part (a piece of 16 Ki
+        // samples takes ~21 us, a step of the matrix-core waves ~0.2 us: half of the matrix part's time), the rest one piece each
         const int items = nstreams * a->mf_npieces, nmf = (int)(((size_t)nstreams * wps + 3) / 4);
-        a->mf_piece_wgs = items;
-        if (mf_dma_applies(log2decim) && n_cu > nmf && n_cu - nmf < items) a->mf_piece_wgs = n_cu - nmf;
+        a->mf_piece_early = 0; a->mf_piece_share = 0;
+        if (mf_dma_applies(log2decim) && n_cu > nmf) {
+            int early = n_cu - nmf;
+            if (early > items) early = items;
+            int share = (int)((W + S) / 6720);
+            if (share < 3) share = 3;
+            if (share > (items + early - 1) / early) share = (items + early - 1) / early;
+            a->mf_piece_early = early; a->mf_piece_share = share;
+        }
+        const int rest = items - a->mf_piece_early * a->mf_piece_share;
+        a->mf_piece_wgs = a->mf_piece_early + (rest > 0 ? rest : 0);
     }
     return true;
 }

@@ -64,7 +64,9 @@ struct DecimArgs {
     // matrix-core waves run mf_wps groups of 8 spans of mf_span raw samples from mf_head on
     size_t mf_head, mf_span, mf_tail_start, mf_tail_seg;
     int mf_wps, mf_npieces;
-    int mf_piece_wgs;         // workgroups that share the nstreams x mf_npieces VALU pieces (decim_mfma_kernel; plan_decimate_mfma)
+    // the nstreams x mf_npieces VALU pieces go to mf_piece_wgs workgroups: the first mf_piece_early of them take mf_piece_share
+    // pieces each (they start with the launch, on the CUs the matrix-core workgroups leave free), every other one a single piece
+    int mf_piece_wgs, mf_piece_early, mf_piece_share;
     unsigned *mf_dump;   // >= 1 KiB of device memory that swallows the stores of the warm-up period
 };
 
