@@ -1,5 +1,4 @@
-// interp_body.h -- the VALU / LDS interpolator cascade (DESIGN.md "K5") as device code shared by interp_kernels.hip (the
-// kernel of its own) and interp_mfma.hip (head and tail segments of every stream next to the matrix-core waves).
+// interp_body.h -- the VALU / LDS interpolator cascade (DESIGN.md "K5") as device code, included by interp_kernels.hip.
 #ifndef SDRHIP_INTERP_BODY_H
 #define SDRHIP_INTERP_BODY_H
 #include "sdrhip_internal.h"

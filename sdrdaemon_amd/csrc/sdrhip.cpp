@@ -184,17 +184,10 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
         else if (v == "mfma") c->opt.decim_path = DECIM_PATH_MFMA;
         else return fail(SDRHIP_EINVAL, "ctx_set_option: decim_path must be auto, valu or mfma");
     } else if (k == "interp_path") {
-        if (v == "auto") { c->opt.interp_mfma = 0; c->opt.interp_wave = CtxOptions().interp_wave; }
-        else if (v == "valu") { c->opt.interp_mfma = 0; c->opt.interp_wave = 0; }
-        else if (v == "wave") { c->opt.interp_mfma = 0; c->opt.interp_wave = 1; }
-        else if (v == "mfma") {
-#ifdef SDRHIP_WITH_K5M
-            c->opt.interp_mfma = 1;
-#else
-            return fail(SDRHIP_EINVAL, "ctx_set_option: this library was built without the matrix-core interpolator experiment (make WITH_K5M=1)");
-#endif
-        }
-        else return fail(SDRHIP_EINVAL, "ctx_set_option: interp_path must be auto, valu, wave or mfma");
+        if (v == "auto") c->opt.interp_wave = CtxOptions().interp_wave;
+        else if (v == "valu") c->opt.interp_wave = 0;
+        else if (v == "wave") c->opt.interp_wave = 1;
+        else return fail(SDRHIP_EINVAL, "ctx_set_option: interp_path must be auto, valu or wave");
     } else if (k == "mfma_span" && isnum) c->opt.mfma_span = (size_t)num;
     else if (k == "mfma_min" && isnum) c->opt.mfma_min = (size_t)num;
     else if (k == "interp_span" && isnum) c->opt.interp_span = (size_t)num;

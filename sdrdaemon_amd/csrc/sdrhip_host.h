@@ -101,13 +101,12 @@ int fec_decode_device(sdrhip_ctx *ctx, const uint8_t *rx, size_t rx_frame_bytes,
 namespace sdrhip {
 enum { DECIM_PATH_AUTO = 0, DECIM_PATH_VALU = 1, DECIM_PATH_MFMA = 2 };
 // Kernel-path knobs of a context.  Read ONCE from the environment when the context is created (SDRHIP_DECIM_PATH =
-// valu | mfma | auto, SDRHIP_MFMA_SPAN, SDRHIP_MFMA_MIN, SDRHIP_INTERP_PATH = valu | mfma, SDRHIP_INTERP_SPAN); afterwards
+// valu | mfma | auto, SDRHIP_MFMA_SPAN, SDRHIP_MFMA_MIN, SDRHIP_INTERP_PATH = valu | wave, SDRHIP_INTERP_SPAN); afterwards
 // only sdrhip_ctx_set_option() changes them (tests, tools), under the context's lock.
 struct CtxOptions {
     int decim_path = DECIM_PATH_AUTO;
     size_t mfma_span = 0;                  // forced span length of the matrix-core decimator (0 = planner's choice)
     size_t mfma_min = (size_t)1 << 22;     // smallest call (samples over all streams, decimate4 / 8) the matrix cores take in auto mode
-    int interp_mfma = 0;
     int interp_wave = 1;                   // interpolate4 .. 64: K5w, the barrier-free wave-private pipeline (interp_wave.h); 0 = K5
     size_t interp_span = 0;
     int rx_fused = 1;                      // pipelined Rx pipe: encoder in the decimator's launch (0 = separate launches)

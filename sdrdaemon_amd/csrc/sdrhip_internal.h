@@ -175,10 +175,6 @@ struct InterpArgs {
     int32_t *state_next;
     int nstreams;
     int nsub_per_seg, nseg;
-    // matrix-core path (interp_mfma.hip): VALU segment 0 and segments >= mf_tail_seg, spans in between
-    size_t mf_head, mf_span;      // inputs
-    int mf_wps, mf_tail_seg, mf_npieces;
-    unsigned *mf_dump;
     // (the fused Tx pipe needs no special input mode: the decoder's 127 x 508 byte payload of a frame is
     // contiguous, i.e. already the linear sample layout)
 };
@@ -187,8 +183,6 @@ void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_s
 // K5w (interp_wave.h): wave-private pipelines (workgroups of one or four independent waves), blocks of 128 inputs; log2interp 2..6
 void plan_interpolate_wave(int log2interp, size_t n_in, int nstreams, int n_cu, size_t seg_override, int *nsub_per_seg, int *nseg);
 hipError_t launch_interpolate_wave(int log2interp, const InterpArgs &a, hipStream_t stream);
-bool plan_interpolate_mfma(int log2interp, size_t n_in, int nstreams, size_t span_override, InterpArgs *a);
-hipError_t launch_interpolate_mfma(int log2interp, const InterpArgs &a, hipStream_t stream);
 
 // frames are processed in groups that share one coefficient matrix (one frame per half-wave)
 constexpr int GF_FRAMES_PER_GROUP = 2;

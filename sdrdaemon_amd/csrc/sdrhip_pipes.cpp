@@ -75,24 +75,14 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
     a.in = in; a.out = out; a.in_stride = in_stride; a.out_stride = out_stride; a.n_in = n_in;
     a.state_cur = p->state[p->cur]; a.state_next = p->state[p->cur ^ 1];
     a.nstreams = p->nstreams;
-    // SDRHIP_INTERP_PATH=mfma selects the matrix-core cascade (interp_mfma.hip, DESIGN.md "K5m": bit-exact but slower
-    // than the VALU kernel, kept as a measured experiment); SDRHIP_INTERP_SPAN = span length in inputs (tests)
-    bool use_mfma = false;
-#ifdef SDRHIP_WITH_K5M
-    if (c->opt.interp_mfma) use_mfma = plan_interpolate_mfma(log2interp, n_in, p->nstreams, c->opt.interp_span, &a);
-#endif
-    const bool use_wave = !use_mfma && c->opt.interp_wave && log2interp >= 2;
+    // SDRHIP_INTERP_PATH = wave (K5w, default) | valu (K5); SDRHIP_INTERP_SPAN = segment length in inputs (tests)
+    const bool use_wave = c->opt.interp_wave && log2interp >= 2;
     if (use_wave) plan_interpolate_wave(log2interp, n_in, p->nstreams, c->n_cu, c->opt.interp_span, &a.nsub_per_seg, &a.nseg);
-    else if (!use_mfma) plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
-    a.mf_dump = c->decim_dump;
+    else plan_interpolate(log2interp, n_in, p->nstreams, &a.nsub_per_seg, &a.nseg);
     hipError_t e;
     {
         KTimer kt(c, SDRHIP_K_INTERPOLATE);
-#ifdef SDRHIP_WITH_K5M
-        e = use_mfma ? launch_interpolate_mfma(log2interp, a, c->stream) : use_wave ? launch_interpolate_wave(log2interp, a, c->stream) : launch_interpolate(log2interp, a, c->stream);
-#else
         e = use_wave ? launch_interpolate_wave(log2interp, a, c->stream) : launch_interpolate(log2interp, a, c->stream);
-#endif
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "interpolate launch: %s", hipGetErrorString(e));
     p->cur ^= 1;
@@ -630,18 +620,26 @@ int rx_launch_batch(sdrhip_rx *rx, sdrhip_rx::Batch &b)
         i = j;
     }
     b.in.mark(c->stream);
+    // everything that can fail for want of memory happens BEFORE the samples are consumed: a batch that failed here is launched again
+    // by the next submit / collect, one that fails behind sdrhip_rx_process is dropped (its samples are in the filter state already;
+    // replaying them would duplicate samples and shift every later stamp)
+    b.frame_bytes = (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
+    const size_t nf_max = sdrhip_rx_max_frames(rx, b.n_in);
+    if (nf_max && (rc = b.out.reserve((size_t)S * nf_max * b.frame_bytes))) return rc;
+    if (!b.done && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) { b.done = nullptr; return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
     size_t nf = 0;
     rc = sdrhip_rx_process(rx, b.din.as<int16_t>(), b.n_in, dstride, b.tv_sec, b.tv_usec, nullptr, 0, &nf, SDRHIP_MEM_DEVICE);
-    if (rc) return rc;
+    if (rc) return rc; // (refused before any launch, or a launch failure: the pipe's own error)
     b.frames = nf;
-    b.frame_bytes = (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
-    if (nf) {
-        if ((rc = b.out.reserve((size_t)S * nf * b.frame_bytes))) return rc;
-        if (S == 1) HIP_TRY(hipMemcpyAsync(b.out.p, rx->view_base, nf * b.frame_bytes, hipMemcpyDeviceToHost, c->stream));
-        else HIP_TRY(hipMemcpy2DAsync(b.out.p, nf * b.frame_bytes, rx->view_base, rx->view_stride, nf * b.frame_bytes, S, hipMemcpyDeviceToHost, c->stream));
+    hipError_t e = hipSuccess;
+    if (nf > nf_max) e = hipErrorInvalidValue; // (cannot happen: rx_max_frames is the pipe's own bound)
+    else if (nf && S == 1) e = hipMemcpyAsync(b.out.p, rx->view_base, nf * b.frame_bytes, hipMemcpyDeviceToHost, c->stream);
+    else if (nf) e = hipMemcpy2DAsync(b.out.p, nf * b.frame_bytes, rx->view_base, rx->view_stride, nf * b.frame_bytes, S, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(b.done, c->stream);
+    if (e != hipSuccess) {
+        b.state = 0; // consumed and lost: never replayed
+        return fail(SDRHIP_EDEVICE, "rx batch download: %s (the batch's %zu frames per stream are lost)", hipGetErrorString(e), nf);
     }
-    if (!b.done) HIP_TRY(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(b.done, c->stream));
     b.state = 2;
     return SDRHIP_OK;
 }
@@ -697,17 +695,20 @@ extern "C" int sdrhip_rx_submit(sdrhip_rx *rx, const int16_t *iq_in, size_t n_in
     if (b.state == 2) return fail(SDRHIP_EBUSY, "rx_submit: every batch of the ring is in flight: sdrhip_rx_collect first");
     if (b.state == 0) {
         b.blocks.clear(); b.strides.clear(); b.n_in = 0; b.tv_sec = tv_sec; b.tv_usec = tv_usec; b.state = 1;
+        b.in_cap = 0; // no staged rows yet: the first pageable block of this batch (re)claims the arena
     }
     if (host_is_pinned(iq_in, ((size_t)(S - 1) * in_stride + n_in) * 4)) {
         b.blocks.push_back(std::make_pair(iq_in, n_in)); // in place: the caller keeps it untouched until the batch is collected
         b.strides.push_back(in_stride);
     } else {
         // staged: row s of the pinned arena holds stream s, the block at the batch's current sample offset
+        // (in-place blocks in front of it leave their part of the rows unused: a block always sits at its batch offset)
         const size_t need = b.n_in + n_in;
-        if (b.n_in == 0) {
-            b.in_cap = (size_t)rx->a_blocks * n_in > need ? (size_t)rx->a_blocks * n_in : need;
-            int rc = b.in.reserve((size_t)S * b.in_cap * 4); // (waits for the upload of the batch that used this buffer last)
+        if (b.in_cap == 0) { // first staged block of the batch, whatever came before it in place
+            const size_t cap = (size_t)rx->a_blocks * n_in > need ? (size_t)rx->a_blocks * n_in : need;
+            int rc = b.in.reserve((size_t)S * cap * 4); // (waits for the upload of the batch that used this buffer last)
             if (rc) return rc;
+            b.in_cap = cap;
         } else if (need > b.in_cap) { // blocks longer than the first one: re-lay the rows out in a bigger arena
             PinnedBuf bigger;
             const size_t ncap = 2 * need;

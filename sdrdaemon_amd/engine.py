@@ -551,7 +551,12 @@ class RxPipe:
     def set_async(self, depth=4, blocks=1):
         """ring of `depth` batches, `blocks` submitted blocks per upload + launch + download"""
         check(self.ctx.lib.sdrhip_rx_set_async(self.h, depth, blocks))
-        self._async_cap = 0
+        # samples per stream of the batches not collected yet (oldest first), of the batch being filled and of the batch collected
+        # last (a pipelined pipe delivers the PREVIOUS batch's frames): collect() sizes its buffer from them, not from a lifetime total
+        self._async_blocks = blocks
+        self._async_batches = []
+        self._async_fill = [0, 0]
+        self._async_last = 0
 
     def submit(self, iq, tv_sec=0, tv_usec=0):
         """one block of host samples per stream (numpy; memory from Context.host_alloc is used in place); returns at once.
@@ -563,13 +568,23 @@ class RxPipe:
             x = a  # rows of a bigger array (e.g. a pinned buffer): passed in place with their stride
         else:
             x, _, _ = _bank_view(iq, self.nstreams)
-        self._async_cap = getattr(self, "_async_cap", 0) + x.shape[1]
+        if not hasattr(self, "_async_batches"):  # (sdrhip_rx_submit's default ring: 4 batches of one block)
+            self._async_blocks, self._async_batches, self._async_fill, self._async_last = 1, [], [0, 0], 0
         check(self.ctx.lib.sdrhip_rx_submit(self.h, _ptr(x), x.shape[1], _stride_samples(x), tv_sec, tv_usec))
+        if x.shape[1]:
+            self._async_fill[0] += x.shape[1]
+            self._async_fill[1] += 1
+            if self._async_fill[1] >= self._async_blocks:  # (the library launched the batch)
+                self._async_batches.append(self._async_fill[0])
+                self._async_fill = [0, 0]
 
     def collect(self, wait=True, max_frames=None):
         """-> the finished frames of the oldest batch (S, n, 128 + nb_fec, 512; n may be 0), or None when no batch was collected:
         nothing submitted, or (wait = False) the oldest batch is still in flight / being filled"""
-        cap = max_frames if max_frames is not None else max(getattr(self, "_async_cap", 0) // (SAMPLES_PER_FRAME << self.cfg.log2decim) + 2, 1)
+        batches = getattr(self, "_async_batches", [])
+        fill = getattr(self, "_async_fill", [0, 0])
+        biggest = max([getattr(self, "_async_last", 0), fill[0]] + batches[:1])  # the oldest batch, or its predecessor (pipelined)
+        cap = max_frames if max_frames is not None else max(biggest // (SAMPLES_PER_FRAME << self.cfg.log2decim) + 2, 1)
         fb = (NB_ORIGINAL + self.nb_fec) * UDPSIZE
         nf = C.c_size_t(0)
         for _ in range(2):  # (a batch bigger than the guess -- pipelined mode delivers the previous batch's frames -- is asked for again)
@@ -582,6 +597,11 @@ class RxPipe:
         if rc == -6:
             return None
         check(rc)
+        if batches:
+            self._async_last = batches.pop(0)
+        elif fill[1]:  # (wait = True sent the partly filled batch out as it was)
+            self._async_last = fill[0]
+            self._async_fill = [0, 0]
         return out[:, :nf.value]
 
     def process(self, iq, tv_sec=0, tv_usec=0, out=None):

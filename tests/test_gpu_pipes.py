@@ -453,6 +453,48 @@ def test_rx_submit_collect_equals_the_synchronous_pipe(ctx, oracle, blocks, pinn
         ctx.host_free(src)
 
 
+@pytest.mark.parametrize("order", ["pinned_first", "pageable_first", "alternating"])
+def test_rx_submit_mixes_pinned_and_pageable_blocks_in_one_batch(ctx, order):
+    """a batch whose first block is taken in place (sdrhip_host_alloc memory) and whose next block is pageable
+    used to memcpy from a NULL arena.  Every mix gives the frames of the synchronous pipe; blocks of different lengths included."""
+    import sdrdaemon_amd as sd
+
+    S, lens = 2, [65536, 65536, 98304, 32768, 65536, 65536]
+    tot = sum(lens)
+    xs = np.stack([signals.noise(tot, 900 + s) for s in range(S)])
+    buf = ctx.host_alloc((S, tot, 2))
+    buf[:] = xs
+    pin = {"pinned_first": [True, False, False], "pageable_first": [False, True, True], "alternating": [True, False, True]}[order]
+    ref = sd.RxPipe(ctx, S, log2decim=3, nb_fec=16)
+    p = sd.RxPipe(ctx, S, log2decim=3, nb_fec=16)
+    p.set_async(depth=1, blocks=3)
+    lo = 0
+    for rnd in range(2):  # the second batch reuses the first one's arena (a ring of one batch)
+        lo0 = lo
+        for k in range(3):
+            n = lens[3 * rnd + k]
+            p.submit((buf if pin[k] else xs)[:, lo:lo + n], 5 + rnd, 0)
+            lo += n
+        got = p.collect(wait=True)
+        exp = ref.process(xs[:, lo0:lo], 5 + rnd, 0)
+        assert got.shape == exp.shape and got.shape[1] > 0 and np.array_equal(got, exp), (order, rnd)
+    ctx.host_free(buf)
+
+
+def test_rx_collect_buffer_does_not_grow_with_the_stream(ctx):
+    """the binding sized collect()'s buffer from a lifetime total of submitted samples; it follows the batches
+    still outstanding now"""
+    import sdrdaemon_amd as sd
+
+    rx = sd.RxPipe(ctx, 1, log2decim=4, nb_fec=8)
+    rx.set_async(depth=2, blocks=1)
+    x = signals.noise(16129 * 16 + 64, 3)
+    for i in range(40):
+        rx.submit(x, i, 0)
+        got = rx.collect(wait=True)
+        assert got.shape[1] >= 1 and got.base is not None and got.base.shape[1] <= 4, (i, got.base.shape)
+
+
 def test_rx_collect_refuses_a_buffer_that_is_too_small(ctx):
     """sdrhip_rx_collect knows the caller's capacity (max_frames): a batch that holds more frames stays uncollected, the count
     comes back with SDRHIP_EINVAL, a second call with room gets the frames"""
