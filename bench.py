@@ -49,6 +49,100 @@ BYTES_DECIM = 4.0 + 4.0 / 16.0                      # kernel K1: read int16 IQ, 
 BYTES_CONFIG3 = 4.0 + 160.0 * 512.0 / 258064.0      # whole pipe incl. the 160 x 512 B frames
 
 
+class BoxState:
+    """Socket power and shader clock of the GPU while the benchmark runs (both dominant kernels run at the board's
+    power cap and boxes differ by ~10 % in what they make of it -- a line without these cannot tell a slow kernel from a hot box).
+    A thread polls amdsmi (in-process, ~1 ms per sample; fallback: the amdgpu hwmon files) between start() and stop();
+    summary() -> {"power_w": mean, "power_w_max", "sclk_mhz": mean, "sclk_mhz_min", "samples", "power_cap_w", "source"} or None."""
+
+    def __init__(self, index=0, period_s=0.002):
+        import threading
+
+        self.index, self.period = index, period_s
+        self.rows, self._stop, self._thr = [], threading.Event(), None
+        self.cap_w, self.source, self._read = None, None, None
+        try:
+            import amdsmi
+
+            amdsmi.amdsmi_init()
+            h = amdsmi.amdsmi_get_processor_handles()[index]
+
+            def read():
+                p = amdsmi.amdsmi_get_power_info(h)
+                w = p.get("current_socket_power") or p.get("socket_power") or p.get("average_socket_power")
+                c = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                return float(w), float(c.get("clk") or c.get("cur_clk"))
+
+            read()
+            self._read, self.source = read, "amdsmi (current_socket_power, GFX clk)"
+            try:
+                cap = amdsmi.amdsmi_get_power_cap_info(h).get("power_cap")
+                self.cap_w = float(cap) / (1e6 if cap and cap > 1e5 else 1.0)
+            except Exception:
+                pass
+        except Exception:
+            self._read = self._hwmon_reader()
+
+    def _hwmon_reader(self):
+        import glob
+
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        if self.index >= len(cards):
+            return None
+        d = cards[self.index]
+        pw = [f for f in (d + "/power1_input", d + "/power1_average") if os.path.exists(f)]
+        fq = d + "/freq1_input"
+        if not pw or not os.path.exists(fq):
+            return None
+        self.source = "amdgpu hwmon (%s, freq1_input)" % os.path.basename(pw[0])
+
+        def read():
+            with open(pw[0]) as f:
+                w = float(f.read()) / 1e6
+            with open(fq) as f:
+                c = float(f.read()) / 1e6
+            return w, c
+        try:
+            read()
+        except Exception:
+            return None
+        return read
+
+    def start(self):
+        import threading
+
+        if self._read is None or self._thr is not None:
+            return self
+        self.rows = []
+        self._stop.clear()
+
+        def loop():
+            while not self._stop.is_set():
+                try:
+                    self.rows.append(self._read())
+                except Exception:
+                    pass
+                self._stop.wait(self.period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join()
+            self._thr = None
+        return self.summary()
+
+    def summary(self):
+        rows = [r for r in self.rows if r[0] > 0]
+        if not rows:
+            return None
+        pw, ck = [r[0] for r in rows], [r[1] for r in rows]
+        return {"power_w": round(sum(pw) / len(pw), 1), "power_w_max": round(max(pw), 1), "sclk_mhz": round(sum(ck) / len(ck), 1),
+                "sclk_mhz_min": round(min(ck), 1), "samples": len(rows), "power_cap_w": self.cap_w, "source": self.source}
+
+
 def make_input(ctx, device, n, seeds, kind):
     """-> (len(seeds), n, 2) int16 on the device.  noise: uniform full-scale int16 (the stress input of BASELINE.md 3.4,
     worst case for toggling); testsource: the library's TestSource bank (10 Msps, -20 dB CW at +100 kHz + 1 kHz per
@@ -235,7 +329,7 @@ def roof(bytes_per_launch, launch_ms, kernel, traffic=None):
     return r
 
 
-def extra_configs(ctx, dev, x, kind):
+def extra_configs(ctx, dev, x, kind, ids):
     """The other single-GPU configurations of BASELINE.json, same process, same input tensors (VERDICT r1 #4)."""
     import sdrdaemon_amd as sd
     from sdrdaemon_amd.engine import K_DECIMATE, K_FEC_DECODE, K_INTERPOLATE
@@ -249,21 +343,31 @@ def extra_configs(ctx, dev, x, kind):
     out.append({"config": "configs[1]: %d streams x 2^%d samples, decimate16_cen (EO1), FEC off" % (S, n.bit_length() - 1),
                 "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
                 "roofline": roof(BYTES_DECIM * S * n, per[K_DECIMATE], decim_kernel_name(d.last_plan()),
-                                 pmc_traffic(float(S) * n, decim_kernel_name(d.last_plan())))})
-    del y
-    # the headline workload through the pipelined plumbing (sdrhip_rx_set_pipelined: frames delivered one call late, the encoder of
-    # call i - 1 inside the decimator launch of call i).  Steady state: every timed step holds one decimation and one encode.
-    rxp = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
-                    center_frequency_khz=435000, sample_rate=625000, pipelined=True)
-    wall, per = timed_steps(ctx, lambda: rxp.process_view(x, tv_sec=1, tv_usec=0), [K_DECIMATE])
-    rxp.flush_view()
-    out.append({"config": "configs[2] x %d streams, pipelined plumbing: frames delivered one call late, CM256 encoder workgroups inside the "
-                          "decimator's launch (rx_fused_kernel)" % S,
-                "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
-                "roofline": roof(BYTES_CONFIG3 * S * n, per[K_DECIMATE], "rx_fused_kernel<4,true> (decimator + encoder of the previous call: "
-                                                                          "config-3 algorithmic bytes, 4.317 B per sample)",
-                                 pmc_traffic(float(S) * n, "rx_fused_kernel<4,true>"))})
-    del rxp
+                                 pmc_traffic(float(S) * n, decim_kernel_name(d.last_plan()))),
+                "verified": verify_decim(ctx, x, ids, kind)})
+    del y, d
+    # the headline workload through the pipelined plumbing (sdrhip_rx_set_pipelined: frames delivered one call late).  Two variants of
+    # where the waiting encode runs: inside the decimator launch of the next call (rx_fused_kernel), or as its own launch on the
+    # context's second stream BESIDE that decimator (LDS-DMA ring of depth 3 so that two encoder workgroups fit on every CU).
+    # Steady state: every timed step holds one decimation and one encode.
+    for fused, label, kern in ((1, "CM256 encoder workgroups inside the decimator's launch (rx_fused_kernel)", "rx_fused_kernel<4,true>"),
+                               (3, "CM256 encoder on the second stream beside the decimator (two streams, ring depth 3)", "decim_mfma_kernel<4,true> (ring 3) || gf_encode128_kernel")):
+        ctx.set_option("rx_fused", fused)
+        try:
+            rxp = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                            center_frequency_khz=435000, sample_rate=625000, pipelined=True)
+            wall, per = timed_steps(ctx, lambda: rxp.process_view(x, tv_sec=1, tv_usec=0), [K_DECIMATE])
+            rxp.flush_view()
+            del rxp
+            out.append({"config": "configs[2] x %d streams, pipelined plumbing: frames delivered one call late, %s" % (S, label),
+                        "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
+                        "roofline": roof(BYTES_CONFIG3 * S * n, wall if fused == 3 else per[K_DECIMATE],
+                                         kern + (" (decimator + encoder of the previous call: config-3 algorithmic bytes, 4.317 B per sample%s)" %
+                                                 ("; the two launches overlap, the step's wall time is the launch time" if fused == 3 else "")),
+                                         pmc_traffic(float(S) * n, kern) if fused == 1 else None),
+                        "verified": verify_step(ctx, x, ids, kind, pipelined=True)})
+        finally:
+            ctx.set_option("rx_fused", 1)
     # configs[2] literally: ONE stream (2^27 samples per step) through the fused Rx pipe
     n1 = 1 << 27
     x1 = make_input(ctx, dev, n1, [4000], kind)
@@ -271,7 +375,9 @@ def extra_configs(ctx, dev, x, kind):
     wall, per = timed_steps(ctx, lambda: rx1.process_view(x1, tv_sec=1, tv_usec=0), [K_DECIMATE])
     out.append({"config": "configs[2] as one stream: 2^27 samples per step, decimate16_cen + framing + CM256 128+32",
                 "ms_per_step": round(wall, 4), "value": round(n1 / wall / 1e3, 1), "unit": "Msamples/s (input)",
-                "roofline": roof(BYTES_DECIM * n1, per[K_DECIMATE], decim_kernel_name(rx1.last_plan()))})
+                "roofline": roof(BYTES_DECIM * n1, per[K_DECIMATE], decim_kernel_name(rx1.last_plan()),
+                                 pmc_traffic(float(n1), decim_kernel_name(rx1.last_plan()) + "@%d" % n1)),
+                "verified": verify_one_stream(ctx, x1, kind)})
     del x1, rx1
     # configs[3]: Tx pipe.  The received frames are config 3's OUTPUT: the first 128 frames of every stream of this very bank
     # through the Rx pipe, 24 of each frame's 160 blocks lost (a DIFFERENT random set in every frame, tests/headline_inputs.py),
@@ -298,7 +404,81 @@ def extra_configs(ctx, dev, x, kind):
                                  pmc_traffic_units(interp_kernel_name(ctx), "outputs_per_launch", nout)),
                 "pipe_gbps_config4": round((4.0 + 128.0 * 512.0 / 258064.0) * nout / (wall * 1e-3) / 1e9, 1),
                 "verified": tx_verified})
+    # configs[3] through the pipelined plumbing (sdrhip_tx_set_pipelined): the decode of batch N on the second stream beside the
+    # interpolator of batch N - 1, samples delivered one call late
+    ctx.set_option("dec_max_rows", NB_FEC)
+    try:
+        txp = sd.TxPipe(ctx, Stx, hi.TX_LOG2_INTERP, pipelined=True)
+        wall, per = timed_steps(ctx, lambda: txp.process(rxf), [K_INTERPOLATE])
+        txp.flush(device=rxf.device)
+        del txp
+        txp_verified = verify_tx_step(ctx, rxf, kind, n, pipelined=True)
+    finally:
+        ctx.set_option("dec_max_rows", 128)
+    out.append({"config": "configs[3], pipelined plumbing: %d streams x %d frames per step, decode of this batch on the second stream beside the "
+                          "interpolator of the previous batch, samples delivered one call late" % (Stx, F),
+                "ms_per_step": round(wall, 4), "value": round(nout / wall / 1e3, 1), "unit": "Msamples/s (output)",
+                "roofline": roof((4.0 + 128.0 * 512.0 / 258064.0) * nout, wall, interp_kernel_name(ctx) + " || gf_decode128_kernel (config-4 algorithmic "
+                                 "bytes, 4.254 B per output; the launches overlap, the step's wall time is the launch time)"),
+                "verified": txp_verified})
     return out
+
+
+def verify_one_stream(ctx, x1, kind):
+    """configs[2] as one stream behind its timed region: the frames of one step on fresh handles against the committed digest
+    (headline_golden.json one27: compiled reference decimator + framer / encoder restatement), else against the VALU path"""
+    import hashlib
+
+    import sdrdaemon_amd as sd
+
+    def digest(path):
+        ctx.set_option("decim_path", path)
+        try:
+            rx = sd.RxPipe(ctx, 1, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                           center_frequency_khz=435000, sample_rate=625000)
+            fr = rx.process_view(x1, tv_sec=1, tv_usec=0).torch()
+            ctx.synchronize()
+            return hashlib.sha256(fr[0].contiguous().cpu().numpy().tobytes()).hexdigest()
+        finally:
+            ctx.set_option("decim_path", "auto")
+
+    got = digest("auto")
+    what = "sha256 of the stream's whole frame stream of one step"
+    if kind == "hash":
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "headline_golden.json")) as f:
+                b = json.load(f)["one27"]
+            if (1 << b["log2n"]) == x1.shape[1] and b["seeds"] == [4000]:
+                return {"ok": got == b["frames_sha256"][0], "what": what,
+                        "against": "tests/golden/headline_golden.json one27 (compiled reference decimate16_cen + framer / CM256 restatement)"}
+        except Exception:
+            pass
+    return {"ok": got == digest("valu"), "what": what, "against": "the VALU kernel path of this library on the same input"}
+
+
+def strong_layout_at_one_gpu(ctx, dev, n, kind, total=64):
+    """The job `bench.py --gpus N` runs for every N > 1 -- SURVEY 8e's fixed bank of 64 streams, stream s on rank s mod N -- at
+    N = 1 (the N = 1 point of a scaling curve must be the same job as N = 2 .. 8; the headline step above is its
+    per-GPU share at N = 8).  Same call, 64 streams on the one GPU; verified against the committed reference digests of the
+    64 x 2^25 bank (headline_golden.json bank64_25) when the geometry matches."""
+    import sdrdaemon_amd as sd
+    from sdrdaemon_amd import sharding
+    from sdrdaemon_amd.engine import K_DECIMATE
+
+    ids = sharding.stream_ids_strong(0, 1, total)
+    x = make_input(ctx, dev, n, [1000 + sid for sid in ids], kind)
+    rx = sd.RxPipe(ctx, total, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                   center_frequency_khz=435000, sample_rate=625000)
+    wall, per = timed_steps(ctx, lambda: rx.process_view(x, tv_sec=1, tv_usec=0), [K_DECIMATE], steps=12)
+    plan = rx.last_plan()
+    del rx
+    line = {"config": "configs[4]'s job at N = 1: the strong layout's %d streams x 2^%d samples on one GPU (what --gpus 2 / 4 / 8 shard s mod N)" % (total, n.bit_length() - 1),
+            "layout": "strong", "streams_total": total, "stream_ids": ids,
+            "ms_per_step": round(wall, 4), "value": round(total * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
+            "roofline": roof(BYTES_DECIM * total * n, per[K_DECIMATE], decim_kernel_name(plan)),
+            "verified": verify_step(ctx, x, ids, kind)}
+    del x
+    return line
 
 
 def interp_kernel_name(ctx):
@@ -306,7 +486,7 @@ def interp_kernel_name(ctx):
     return "interp_kernel<4>" if os.environ.get("SDRHIP_INTERP_PATH", "auto") == "valu" else "interp_wave_kernel<4, 4>"
 
 
-def verify_tx_step(ctx, rxf, kind, n):
+def verify_tx_step(ctx, rxf, kind, n, pipelined=False):
     """Behind the timed Tx region: the SAME call (dec_max_rows still at the sender's fecblk) on a fresh handle, whole-output
     digests per stream.  With the default `hash` input and bench.py's own geometry the expected digests are the committed ones
     (tests/golden/headline_golden.json "tx_bank8": oracle cm256_decode + the compiled reference's interpolate16_cen); otherwise
@@ -319,8 +499,11 @@ def verify_tx_step(ctx, rxf, kind, n):
     S, F = rxf.shape[0], rxf.shape[1]
 
     def digests():
-        tx = sd.TxPipe(ctx, S, hi.TX_LOG2_INTERP)
+        tx = sd.TxPipe(ctx, S, hi.TX_LOG2_INTERP, pipelined=pipelined)
         iq = tx.process(rxf)
+        if pipelined:  # (the first call delivers nothing; the batch comes out one call -- here: a flush -- late)
+            assert iq.shape[1] == 0
+            iq = tx.flush(device=rxf.device)
         ctx.synchronize()
         return [hashlib.sha256(iq[s].contiguous().cpu().numpy().tobytes()).hexdigest() for s in range(S)]
 
@@ -349,7 +532,51 @@ def verify_tx_step(ctx, rxf, kind, n):
             "against": "the dense decoder path of this library on the same input (no committed digest for this geometry)"}
 
 
-def verify_step(ctx, x, ids, kind):
+def _gold_bank(n, ids):
+    """the committed reference digests (tests/golden/headline_golden.json) of the bank that holds exactly these streams, or None"""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "headline_golden.json")) as f:
+            H = json.load(f)
+        for name in ("bank8", "bank64_25", "bank64"):
+            b = H[name]
+            if (1 << b["log2n"]) == n and all((1000 + sid) in b["seeds"] for sid in ids):
+                return b, [b["seeds"].index(1000 + sid) for sid in ids]
+    except Exception:
+        pass
+    return None, None
+
+
+def verify_decim(ctx, x, ids, kind):
+    """configs[1] behind its timed region: decimate16_cen of the bank on fresh handles, whole-output digest per stream against the
+    committed digests of the compiled reference (hash input, bench.py's geometry), else against the VALU kernel path."""
+    import hashlib
+
+    import sdrdaemon_amd as sd
+
+    S, n = x.shape[0], x.shape[1]
+
+    def digests(path):
+        ctx.set_option("decim_path", path)
+        try:
+            d = sd.Decimators(ctx, S, sd.HB_EO1)
+            y, _ = d.decimate(LOG2DECIM, sd.FC_CEN, 16, x)
+            ctx.synchronize()
+            return [hashlib.sha256(y[s].contiguous().cpu().numpy().tobytes()).hexdigest() for s in range(S)], d.last_plan()["path"]
+        finally:
+            ctx.set_option("decim_path", "auto")
+
+    got, path = digests("auto")
+    b, idx = _gold_bank(n, ids) if kind == "hash" else (None, None)
+    what = "sha256 of every stream's whole decimated output of one step"
+    if b is not None:
+        return {"ok": got == [b["dec_sha256"][i] for i in idx], "streams": S, "kernel_path": path, "what": what,
+                "against": "tests/golden/headline_golden.json dec_sha256 (the compiled reference's decimate16_cen)"}
+    exp, _ = digests("valu")
+    return {"ok": got == exp, "streams": S, "kernel_path": path, "what": what,
+            "against": "the VALU kernel path of this library on the same input (no committed digest for this geometry)"}
+
+
+def verify_step(ctx, x, ids, kind, pipelined=False):
     """Behind the timed region: the SAME call on fresh handles (streams restart from the constructor state), whole output
     digests.  With the default `hash` input and bench.py's own geometry the expected digests are the committed ones made
     from the compiled reference decimator + the framer / encoder restatement (tests/golden/headline_golden.json); otherwise
@@ -364,8 +591,11 @@ def verify_step(ctx, x, ids, kind):
         ctx.set_option("decim_path", path)
         try:
             rx = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
-                           center_frequency_khz=435000, sample_rate=625000)
+                           center_frequency_khz=435000, sample_rate=625000, pipelined=pipelined)
             fr = rx.process_view(x, tv_sec=1, tv_usec=0).torch()
+            if pipelined:  # (the first call delivers nothing; the SECOND one delivers the first one's frames)
+                assert fr.shape[1] == 0
+                fr = rx.process_view(x, tv_sec=7, tv_usec=9).torch()
             ctx.synchronize()
             return [hashlib.sha256(fr[s].contiguous().cpu().numpy().tobytes()).hexdigest() for s in range(S)], rx.last_plan()["path"]
         finally:
@@ -374,15 +604,9 @@ def verify_step(ctx, x, ids, kind):
     got, path = frames_digests("auto")
     gold = None
     if kind == "hash":
-        try:
-            with open(os.path.join(ROOT, "tests", "golden", "headline_golden.json")) as f:
-                H = json.load(f)
-            for name in ("bank8", "one27", "bank64"):
-                b = H[name]
-                if (1 << b["log2n"]) == n and all((1000 + sid) in b["seeds"] for sid in ids) and name != "one27":
-                    gold = [b["frames_sha256"][b["seeds"].index(1000 + sid)] for sid in ids]
-        except Exception:
-            gold = None
+        b, idx = _gold_bank(n, ids)
+        if b is not None:
+            gold = [b["frames_sha256"][i] for i in idx]
     if gold is not None:
         return {"ok": got == gold, "against": "tests/golden/headline_golden.json (compiled reference decimate16_cen + framer / CM256 restatement)",
                 "streams": S, "kernel_path": path, "what": "sha256 of every stream's whole frame stream of one step"}
@@ -437,6 +661,7 @@ def main():
                     help="the HIP-event timers of the roofline kernel bracket every N-th step of the timed region (default 4)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: leave the per-kernel HIP events out of the timed region (roofline fields become null)")
+    ap.add_argument("--no-box-state", action="store_true", help="do not sample socket power / shader clock (amdsmi) beside the timed region")
     ap.add_argument("--force-dist", action="store_true",
                     help="N = 1 only: go through the N > 1 code path anyway (init_process_group, barriers, device-tensor all_reduce) -- "
                          "executes the nccl = RCCL branch on a one-GPU box")
@@ -444,7 +669,10 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to dry-run the N > 1 path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
     if args.streams is None:
-        args.streams = 64 if args.gpus > 1 else 0
+        # SDRHIP_BENCH_SCALE=1: this run is one point of a 1 / 2 / 4 / 8 sweep -- the N = 1 point is then the SAME job as the
+        # others (SURVEY 8e's bank of 64 streams); without it the one-GPU run is the headline step (8 streams, config 5's per-GPU
+        # share) and reports the 64-stream job as an extra `configs` line
+        args.streams = 64 if (args.gpus > 1 or os.environ.get("SDRHIP_BENCH_SCALE") == "1") else 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as a plain process (the way the driver starts the 1-GPU run): become the launcher of one rank per GPU
         sys.exit(relaunch_under_torchrun(args))
@@ -531,6 +759,22 @@ def main():
     fec_ms, fec_n = ctx.kernel_timing_read(K_FEC_ENCODE)
     ctx.kernel_timing(False)
     ctx.set_option("ktime_stride", 1)
+    # the state of the box: the same step for 0.8 s more, UNTIMED, with the power / clock sampler beside it.  Not inside the timed
+    # region: the SMU's socket power is a filtered value that takes ~0.4 s of load to settle (a 60-ms timed region reads the ramp:
+    # 680 W on a box that settles at 1370 W), and the queries themselves should not sit beside the measurement.
+    box_state = None
+    if rank == 0 and not args.no_box_state:
+        box = BoxState(local, period_s=0.01).start()
+        t_s = time.perf_counter()
+        while time.perf_counter() - t_s < 0.8:
+            for _ in range(10):
+                step(0)
+            torch.cuda.synchronize()
+        box.stop()
+        box.rows = box.rows[len(box.rows) // 2:]  # the settled half
+        box_state = box.summary()
+        if box_state is not None:
+            box_state["over"] = "the second half of 0.8 s of the same step, back to back, right behind the timed region (untimed)"
     plan = rx.last_plan()
     kname = decim_kernel_name(plan)
     verified = None if args.no_verify else verify_step(ctx, x, ids, args.input)
@@ -560,6 +804,8 @@ def main():
                                    "CM256 128+32 encode" % (("%d streams over %d GPU(s) (configs[4] when 64 over 8)" % (args.streams, world))
                                                             if args.streams else "%d streams/GPU" % S),
                        "streams_per_gpu": S, "streams_total": args.streams if args.streams else S * world,
+                       "layout": ("strong: the fixed bank of %d streams, stream s on rank s mod %d (SURVEY 8e; the same job at every N)" % (args.streams, world))
+                                 if args.streams else "weak: %d streams per rank, stream id = rank * %d + s (N = 8: BASELINE configs[4])" % (S, S),
                        "samples_per_stream_per_step": n, "log2decim": LOG2DECIM, "fcpos": "cen",
                        "nb_fec": NB_FEC, "hb_variant": "EO1", "frames_per_stream_per_step": frames // max(args.steps, 1), "output": "zero-copy view of the frame area",
                        "parallelism": "stream-sharded x%d, no data-path collective" % world,
@@ -573,6 +819,9 @@ def main():
                          "fec_encode_avg_launch_ms": round(fec_ms / max(fec_n, 1), 4), "fec_encode_launches": fec_n},
         }
         res["verified"] = verified
+        # the state of the box the line was measured on: both dominant kernels are limited by the board's power cap,
+        # so ms_per_step on another box scales with what that box's silicon and cooling make of the cap
+        res["box"] = box_state
         lane_ops = pmc_valu_lane_ops(per_launch_samples, kname)
         if lane_ops and dec_n:
             # secondary figure of SURVEY.md 8(d): integer VALU issue, every op counted at the 16-lane / clk rate
@@ -580,7 +829,10 @@ def main():
             res["roofline"]["valu"] = {"achieved": round(tl, 2), "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "T lane-ops/s",
                                        "frac": round(tl / VALU_PEAK_TLANEOPS, 4), "lane_ops_per_sample": round(lane_ops / per_launch_samples, 2)}
         if world == 1 and not args.no_configs:
-            res["configs"] = extra_configs(ctx, dev, x, args.input)
+            res["configs"] = extra_configs(ctx, dev, x, args.input, ids)
+            if not args.streams:
+                del x
+                res["configs"].append(strong_layout_at_one_gpu(ctx, dev, n, args.input))
         if world == 1 and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             res["gpu_over_cpu_1core"] = round(value / res["cpu_baseline"]["value"], 1)

@@ -306,6 +306,37 @@ void sdrhip_tx_destroy(sdrhip_tx *tx);
 int sdrhip_tx_reconfigure(sdrhip_tx *tx, int log2interp);
 int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t *indices, size_t nframes,
                       size_t rx_stride_bytes, int16_t *iq_out, size_t out_stride, size_t *n_out, int mem);
+/* Pipelined mode (off by default).  The reference's Tx chain lives with one frame of latency already: SDRdaemonFECBuffer hands a
+ * frame out when the NEXT frame's first block arrives (SDRdaemonFECBuffer.cpp:133-139), and a reader thread keeps receiving while
+ * the main loop interpolates (sdrdaemontx.cpp:449-498).  With on != 0 a sdrhip_tx_process call decodes ITS batch on the
+ * context's second stream (planner + syndrome decoder: VALU / LDS-latency work) while the first stream interpolates the batch
+ * the PREVIOUS call decoded (store-bound), and DELIVERS that previous batch: iq_out / out_stride / *n_out describe the previous
+ * batch's samples (sdrhip_tx_pending_samples() per stream before the call; 0 after the first call or a flush -- iq_out may then
+ * be NULL).  Same samples, one call later; a waiting batch keeps the interpolation factor it was handed in with.
+ * sdrhip_tx_flush delivers the batch the last call decoded (end of stream, before switching the mode off).  A DEVICE rx buffer
+ * of a pipelined call is read by the second stream after the call returns: leave it untouched until the next
+ * sdrhip_tx_process / sdrhip_tx_flush on this handle has returned.  (Context option "tx_overlap" = 0: the same one-call-late
+ * delivery with both kernels on the first stream, the A / B partner.) */
+int sdrhip_tx_set_pipelined(sdrhip_tx *tx, int on);
+int sdrhip_tx_flush(sdrhip_tx *tx, int16_t *iq_out, size_t out_stride, size_t *n_out, int mem);
+size_t sdrhip_tx_pending_samples(const sdrhip_tx *tx);
+/* Asynchronous host-pointer entry, the Tx twin of sdrhip_rx_submit / sdrhip_rx_collect.  sdrdaemontx receives on a reader thread
+ * while the main loop interpolates (sdrdaemontx.cpp:449-498) and its collector releases a frame one frame late
+ * (SDRdaemonFECBuffer.cpp:133-139).  sdrhip_tx_submit takes ONE batch of received frames from host memory (rx, indices,
+ * nframes, rx_stride_bytes as in sdrhip_tx_process; staged through pinned memory, or used in place when it lies in
+ * sdrhip_host_alloc memory, which the caller then leaves untouched until the batch is collected), enqueues upload + decode +
+ * interpolate + download on the context's stream and returns at once.  sdrhip_tx_collect returns the OLDEST batch: its
+ * nframes * 16129 << log2interp samples per stream (stream s at iq_out + 2 * s * out_stride; iq_out has room for max_samples per
+ * stream: a bigger batch stays uncollected, *n_out says how many, the call returns SDRHIP_EINVAL) and, when block0_out is not
+ * NULL, the frames' meta blocks (super block 0: nstreams * nframes x 508 bytes, stream-major) -- with log2interp = 0 the two
+ * together are exactly what SDRdaemonFECBuffer hands out per frame (getSlotData + the meta block, .cpp:72-110).  SDRHIP_OK: one
+ * batch collected (*n_out samples per stream, *n_frames frames); SDRHIP_EBUSY: none -- nothing submitted, or (wait = 0) the oldest
+ * batch is still in flight; wait = 1 blocks outside the context lock.  At most `depth` batches are in flight (default 4);
+ * sdrhip_tx_submit returns SDRHIP_EBUSY when the ring is full.  The factor in force at submit time applies to the batch. */
+int sdrhip_tx_set_async(sdrhip_tx *tx, int depth);
+int sdrhip_tx_submit(sdrhip_tx *tx, const uint8_t *rx, const uint8_t *indices, size_t nframes, size_t rx_stride_bytes);
+int sdrhip_tx_collect(sdrhip_tx *tx, int16_t *iq_out, size_t out_stride, size_t max_samples, uint8_t *block0_out, size_t *n_out,
+                      size_t *n_frames, int wait);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ EXPORTS = [
     "sdrhip_decimators_reset", "sdrhip_decimate", "sdrhip_interpolators_create", "sdrhip_interpolators_destroy",
     "sdrhip_interpolators_reset", "sdrhip_interpolate", "sdrhip_cm256_encode", "sdrhip_cm256_decode",
     "sdrhip_fec_encode_frames", "sdrhip_fec_decode_frames", "sdrhip_rx_create", "sdrhip_rx_destroy", "sdrhip_rx_reconfigure", "sdrhip_rx_process",
-    "sdrhip_rx_max_frames", "sdrhip_rx_frames_view", "sdrhip_tx_create", "sdrhip_tx_destroy", "sdrhip_tx_reconfigure", "sdrhip_tx_process",
+    "sdrhip_rx_max_frames", "sdrhip_rx_frames_view", "sdrhip_tx_create", "sdrhip_tx_destroy", "sdrhip_tx_reconfigure", "sdrhip_tx_process", "sdrhip_tx_set_pipelined", "sdrhip_tx_flush", "sdrhip_tx_pending_samples", "sdrhip_tx_set_async", "sdrhip_tx_submit", "sdrhip_tx_collect",
     "sdrhip_testsource_create", "sdrhip_testsource_destroy", "sdrhip_testsource_configure", "sdrhip_testsource_get", "sdrhip_testsource_read",
 ]
 
@@ -114,6 +114,13 @@ def load():
     lib.sdrhip_tx_destroy.argtypes = [vp]
     lib.sdrhip_tx_destroy.restype = None
     lib.sdrhip_tx_process.argtypes = [vp, vp, vp, sz, sz, vp, sz, C.POINTER(sz), i]
+    lib.sdrhip_tx_set_pipelined.argtypes = [vp, i]
+    lib.sdrhip_tx_flush.argtypes = [vp, vp, sz, C.POINTER(sz), i]
+    lib.sdrhip_tx_pending_samples.argtypes = [vp]
+    lib.sdrhip_tx_pending_samples.restype = sz
+    lib.sdrhip_tx_set_async.argtypes = [vp, i]
+    lib.sdrhip_tx_submit.argtypes = [vp, vp, vp, sz, sz]
+    lib.sdrhip_tx_collect.argtypes = [vp, vp, sz, sz, vp, C.POINTER(sz), C.POINTER(sz), i]
     lib.sdrhip_testsource_create.argtypes = [vp, i, C.POINTER(vp)]
     lib.sdrhip_testsource_destroy.argtypes = [vp]
     lib.sdrhip_testsource_destroy.restype = None

@@ -6,10 +6,13 @@
 //            first datagram of ANOTHER frame arrives (one frame of latency, SDRdaemonFECBuffer.cpp:133-139).
 //   collector keeps the FIRST 128 super blocks of a frame in arrival order (.cpp:143-166); later blocks are only
 //            counted.  Unlike the reference it does not decode frame by frame: read() drains whatever the socket
-//            already holds, and every released frame that used recovery blocks goes to the GPU in ONE
-//            sdrhip_fec_decode_frames call (plan + scatter + apply on the device, up to MAXBATCH frames); frames
+//            already holds, and every released frame that used recovery blocks goes to the GPU in ONE asynchronous
+//            batch (sdrhip_tx_submit on a Tx pipe with interpolation factor 1: upload + plan + decode + download
+//            enqueued, the call returns; up to MAXBATCH frames, up to 4 batches in flight); frames
 //            without recovery blocks, and incomplete ones (holes stay zero, "incomplete frame" is logged), are put
-//            together on the host.  Results wait in a queue; read() hands them out one per call, together with the
+//            together on the host.  Results wait in a queue; read() hands them out one per call -- a frame whose batch
+//            is still on the GPU is waited for only when its turn comes (sdrhip_tx_collect), the datagrams of the next
+//            frames are taken off the socket meanwhile -- together with the
 //            statistics of that frame (getCurNbBlocks ... getMaxNbRecovery, status string) and the stream meta data.
 //   quirks kept: the very first read() returns the collector's initial (zeroed) slot; getSampleBytes() /
 //            getSampleBits() stay at the base class defaults (the reference never updates them); exactly one
@@ -48,13 +51,19 @@ public:
 #pragma pack(pop)
 
     UDPSourceFEC(const std::string &address, unsigned int port)
-        : UDPSource(address, port, UDPSOURCEFEC_UDPSIZE), m_ctx(0), m_curNbBlocks(0), m_curNbRecovery(0), m_minNbBlocks(256),
-          m_maxNbRecovery(0)
+        : UDPSource(address, port, UDPSOURCEFEC_UDPSIZE), m_ctx(0), m_tx(0), m_seqNext(0), m_seqFront(0), m_curNbBlocks(0), m_curNbRecovery(0),
+          m_minNbBlocks(256), m_maxNbRecovery(0)
     {
         const char *dev = std::getenv("SDRHIP_DEVICE");
         if (sdrhip_ctx_create(dev ? std::atoi(dev) : 0, 0, &m_ctx) != SDRHIP_OK) {
             std::cerr << "UDPSourceFEC: no GPU context (" << sdrhip_last_error() << "): cannot recover lost blocks" << std::endl;
             m_ctx = 0;
+        }
+        // the decoder: a Tx pipe with interpolation factor 1 = SDRdaemonFECBuffer's decode + getSlotData, asynchronous entry
+        if (m_ctx && (sdrhip_tx_create(m_ctx, 1, 0, &m_tx) != SDRHIP_OK || sdrhip_tx_set_async(m_tx, MAXINFLIGHT) != SDRHIP_OK)) {
+            std::cerr << "UDPSourceFEC: no decoder (" << sdrhip_last_error() << "): cannot recover lost blocks" << std::endl;
+            if (m_tx) sdrhip_tx_destroy(m_tx);
+            m_tx = 0;
         }
         initMeta(m_currentMeta);
         initMeta(m_outputMeta);
@@ -64,6 +73,7 @@ public:
 
     virtual ~UDPSourceFEC()
     {
+        if (m_tx) sdrhip_tx_destroy(m_tx);
         if (m_ctx) sdrhip_ctx_destroy(m_ctx);
     }
 
@@ -86,6 +96,7 @@ public:
             }
             decodeClosed();
         }
+        while (m_ready.front().pending) collectBatch(); // its batch is still on the GPU: now it is needed
         Ready &r = m_ready.front();
         samples_out.resize((size_t)(NB - 1) * BLOCK / 4);
         std::memcpy(&samples_out[0], &r.frame[BLOCK], (size_t)(NB - 1) * BLOCK); // blocks 1..127
@@ -100,6 +111,7 @@ public:
         if (m_curNbBlocks < m_minNbBlocks) m_minNbBlocks = m_curNbBlocks;
         if (m_curNbRecovery > m_maxNbRecovery) m_maxNbRecovery = m_curNbRecovery;
         m_ready.pop_front();
+        ++m_seqFront;
     }
 
     /** appends ":<status>:<min blocks>/<max recovery>" (UDPSourceFEC.cpp:80-95) */
@@ -139,7 +151,8 @@ private:
                   << std::endl;
     }
 
-    static const int MAXBATCH = 8; // frames per GPU call
+    static const int MAXBATCH = 8;    // frames per GPU batch
+    static const int MAXINFLIGHT = 4; // batches in flight
 
     // a frame being collected / released: the first 128 super blocks as they arrived, headers included
     struct Collect {
@@ -155,7 +168,8 @@ private:
         std::vector<unsigned char> frame;
         int count, nrec;
         bool meta, decoded;
-        Ready() : frame((size_t)NB * BLOCK, 0), count(0), nrec(0), meta(false), decoded(false) {}
+        bool pending; // its recovered blocks are still on the GPU (a submitted batch)
+        Ready() : frame((size_t)NB * BLOCK, 0), count(0), nrec(0), meta(false), decoded(false), pending(false) {}
     };
 
     // one super block into the collector (SDRdaemonFECBuffer.cpp:112-170 without the decode)
@@ -174,14 +188,15 @@ private:
         ++m_open.count;
     }
 
-    // the released frames -> m_ready, in order; those that used recovery blocks through ONE GPU call
+    // the released frames -> m_ready, in order; those that used recovery blocks as ONE asynchronous GPU batch
     void decodeClosed()
     {
-        std::vector<size_t> gpu; // indices into m_ready of the frames that go to the GPU
+        std::vector<unsigned long> seqs; // sequence numbers (position in the hand-out order) of the frames that go to the GPU
         std::vector<unsigned char> rxb;
         for (std::deque<Collect>::iterator it = m_closed.begin(); it != m_closed.end(); ++it) {
             m_ready.push_back(Ready());
             Ready &r = m_ready.back();
+            const unsigned long seq = m_seqNext++;
             r.count = it->count; r.nrec = it->nrec; r.meta = it->meta; r.decoded = it->count >= NB;
             const int have = it->count < NB ? it->count : NB;
             for (int p = 0; p < have; ++p) { // received originals in place
@@ -192,29 +207,54 @@ private:
                 if (it->index >= 0) // (the initial empty slot is released silently)
                     std::cerr << "SDRdaemonFECBuffer::getSlotData: incomplete frame: m_blockCount: " << it->count
                               << " m_recoveryCount: " << it->nrec << std::endl;
-            } else if (it->nrec > 0 && m_ctx) {
-                gpu.push_back(m_ready.size() - 1);
+            } else if (it->nrec > 0 && m_tx) {
+                seqs.push_back(seq);
                 rxb.insert(rxb.end(), it->rx.begin(), it->rx.end());
             }
         }
         m_closed.clear();
-        if (gpu.empty()) return;
-        std::vector<unsigned char> payload(gpu.size() * (size_t)(NB - 1) * BLOCK), b0(gpu.size() * (size_t)BLOCK);
-        if (sdrhip_fec_decode_frames(m_ctx, &rxb[0], 0, gpu.size(), &payload[0], &b0[0], SDRHIP_MEM_HOST) != SDRHIP_OK) {
+        if (seqs.empty()) return;
+        while ((int)m_batches.size() >= MAXINFLIGHT) collectBatch(); // (the ring is full: the oldest batch first)
+        if (sdrhip_tx_submit(m_tx, &rxb[0], 0, seqs.size(), 0) != SDRHIP_OK) {
             std::cerr << "SDRdaemonFECBuffer::writeAndRead: CM256 decode error (" << sdrhip_last_error() << ")" << std::endl;
             return; // the frames keep what was received
         }
-        for (size_t g = 0; g < gpu.size(); ++g) {
-            Ready &r = m_ready[gpu[g]];
+        for (size_t g = 0; g < seqs.size(); ++g) m_ready[seqs[g] - m_seqFront].pending = true;
+        m_batches.push_back(seqs);
+    }
+
+    // the oldest batch back from the GPU: its frames' payload (blocks 1..127) and meta blocks into their Ready entries
+    void collectBatch()
+    {
+        if (m_batches.empty()) { // (cannot happen: a pending frame belongs to a batch) -- never spin on it
+            for (std::deque<Ready>::iterator it = m_ready.begin(); it != m_ready.end(); ++it) it->pending = false;
+            return;
+        }
+        const std::vector<unsigned long> seqs = m_batches.front();
+        m_batches.pop_front();
+        const size_t per = (size_t)(NB - 1) * BLOCK; // bytes of payload per frame = 16129 samples
+        std::vector<unsigned char> payload(seqs.size() * per), b0(seqs.size() * (size_t)BLOCK);
+        size_t n_out = 0, nf = 0;
+        const int rc = sdrhip_tx_collect(m_tx, reinterpret_cast<int16_t *>(&payload[0]), 0, payload.size() / 4, &b0[0], &n_out, &nf, 1);
+        const bool ok = rc == SDRHIP_OK && nf == seqs.size() && n_out * 4 == payload.size();
+        if (!ok) std::cerr << "SDRdaemonFECBuffer::writeAndRead: CM256 decode error (" << sdrhip_last_error() << ")" << std::endl;
+        for (size_t g = 0; g < seqs.size(); ++g) {
+            if (seqs[g] < m_seqFront) continue; // (handed out already: cannot happen, frames wait for their batch)
+            Ready &r = m_ready[seqs[g] - m_seqFront];
+            r.pending = false;
+            if (!ok) continue; // the frame keeps what was received
             std::memcpy(&r.frame[0], &b0[g * BLOCK], BLOCK);
-            std::memcpy(&r.frame[BLOCK], &payload[g * (size_t)(NB - 1) * BLOCK], (size_t)(NB - 1) * BLOCK);
+            std::memcpy(&r.frame[BLOCK], &payload[g * per], per);
         }
     }
 
     sdrhip_ctx *m_ctx;
+    sdrhip_tx *m_tx;
     Collect m_open;
     std::deque<Collect> m_closed;
     std::deque<Ready> m_ready;
+    std::deque<std::vector<unsigned long> > m_batches; // frames (by sequence number) of the batches in flight, oldest first
+    unsigned long m_seqNext, m_seqFront;               // sequence number of the next released frame / of m_ready.front()
     int m_curNbBlocks, m_curNbRecovery, m_minNbBlocks, m_maxNbRecovery;
     MetaDataFEC m_currentMeta, m_outputMeta;
 };

@@ -40,6 +40,9 @@
 #ifndef MF_WAVES
 #define MF_WAVES 2
 #endif
+#ifndef MF_DMA_BURST
+#define MF_DMA_BURST 1 // LDS-DMA ring: DMAs issued per step (1, 2, 4 or 8), see mf_loop_dma
+#endif
 
 namespace sdrhip {
 namespace {
@@ -289,75 +292,122 @@ template <int NS, int I> __device__ __forceinline__ void mf_front2(MfState<NS> &
 //    starts 72 p + 2 (p >> 2) sixteen-byte units into the group: the sixteen lanes of every ds_read_b128 service group
 //    (MI355X_MICROARCH.md, LDS table) then hit sixteen distinct 4-bank columns.
 constexpr int MF_GROUP_BYTES = 9216;             // 8 blocks of 1 KiB + their skew
-constexpr int MF_WAVE_RING = 4 * MF_GROUP_BYTES; // bytes of LDS per wave
+// Ring depth NG (groups per wave): 4 = 36 KiB per wave, 147 KiB per workgroup -- the workgroup owns its CU; 3 = 27 KiB per wave,
+// 108 KiB per workgroup, which leaves 52 KiB of the CU's 160 KiB for two workgroups of ANOTHER kernel (the CM256 encoder of the
+// previous call on a second stream: sdrhip_pipes.cpp, "overlap" mode).  The DMAs run NG - 1 groups (8 (NG - 1) steps) ahead.
+constexpr int mf_wave_ring(int ng) { return ng * MF_GROUP_BYTES; } // bytes of LDS per wave
 // decimate16 only: measured with 3 interleaved rounds (tools/experiments_r03/exp24.sh), register ring against LDS-DMA ring: decimate16 0.2445 / 0.2363 ms,
 // decimate32 0.2512 / 0.2537, decimate64 0.2693 / 0.2947 (their warm-up and the ring's run-ahead past the span grow with the ratio)
-__host__ __device__ constexpr bool mf_dma_applies(int ns) { return ns == 4; } // (period of 32 steps; one workgroup per CU)
+#ifndef MF_DMA_MAX_NS
+#define MF_DMA_MAX_NS 4 // (experiments: 5 / 6 put decimate32 / 64 on the LDS-DMA ring as well -- their unrolled period is 32 steps too)
+#endif
+__host__ __device__ constexpr bool mf_dma_applies(int ns) { return ns >= 4 && ns <= MF_DMA_MAX_NS; } // (period of 32 steps; one workgroup per CU)
 __host__ __device__ constexpr int mf_block_units(int p) { return 72 * p + 2 * (p >> 2); }
 
-template <int SLOT, int D> __device__ __forceinline__ void mf_dma_issue(unsigned ring, unsigned voff, unsigned long long span_base)
+template <int D> __device__ __forceinline__ void mf_dma_issue(unsigned slot, unsigned voff, unsigned long long span_base)
 {
-    constexpr int off = SLOT * MF_GROUP_BYTES + 16 * mf_block_units(D);
+    constexpr int off = 16 * mf_block_units(D);
     // M0 = LDS byte address of the block (wave-uniform); the lanes' 16 bytes land at M0 + 16 * lane
-    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3 nt" ::"v"(voff), "s"(ring), "n"(off), "s"(span_base) : "memory", "scc");
+    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3 nt" ::"v"(voff), "s"(slot), "n"(off), "s"(span_base) : "memory", "scc");
+}
+template <int N> __device__ __forceinline__ void mf_wait_vm()
+{
+    static_assert(N == 0 || N == 7 || N == 8 || N == 15 || N == 16, "vmcnt immediates of the ring");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
 // (A loader-wave variant -- a fifth wave per workgroup issues all DMAs, the compute waves meet it at one s_barrier per group -- was
 // measured slower, 0.244-0.252 ms against 0.232-0.238 ms with the DMAs in the compute waves: tools/experiments_r03/
 // decim_mfma_experiments.patch, MF_LOADER.)
-template <int NS>
+//
+// Ring bookkeeping, for any depth NG: the period has 4 groups (32 steps); absolute group k lives in slot k % NG.  rs[j] / lr[j]
+// (j < NG) are the LDS byte address of the slot that holds group j OF THE CURRENT PERIOD (as M0 base, wave-uniform; as the lane's
+// read address): group G of the period (G may run into the next one) is slot rs[G % NG], and at the end of a period the arrays
+// rotate by 4 % NG (NG = 4: not at all, NG = 3: by one -- three s_mov + three v_mov per 32 steps).  Step i issues the DMA of
+// group i / 8 + NG - 1, span i % 8 into the slot group i / 8 - 1 has just left; the group read next is awaited once per 8 steps:
+// behind its last DMA the wave has issued the NG - 3 + 1 full groups in between and 7 DMAs of the current issue group.
+template <int NS, int NG>
 __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st, const MfConst &k, MfOut &oc, MfFront &fr, unsigned lds_addr,
                                             const char *wbase, size_t S, int nper, int WP, int lane, int p, int comp, int q)
 {
     constexpr int P = mf_period<NS>();
-    static_assert(P == 32, "the ring turns once per period");
+    static_assert(P == 32, "four groups of 8 steps per period");
+    static_assert(NG == 3 || NG == 4, "ring depth");
+    constexpr int LA = NG - 1; // groups the DMAs run ahead
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned ring = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr + (unsigned)wv * MF_WAVE_RING));
+    const unsigned ring = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr + (unsigned)wv * (unsigned)mf_wave_ring(NG)));
     unsigned long long sb[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         const unsigned long long v = (unsigned long long)(wbase + (size_t)d * S * 4);
         sb[d] = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
     }
+    unsigned rs[NG];
     // what this lane reads back: bytes 128 j + 64 comp + 16 q of step j of span p
-    const __attribute__((address_space(3))) char *lrd =
-        (const __attribute__((address_space(3))) char *)(size_t)(ring + 16u * (unsigned)(mf_block_units(0) + 72 * p + 2 * (p >> 2) + 4 * comp + q));
+    const __attribute__((address_space(3))) char *lr[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        rs[j] = ring + (unsigned)(j * MF_GROUP_BYTES);
+        lr[j] = (const __attribute__((address_space(3))) char *)(size_t)(rs[j] + 16u * (unsigned)(mf_block_units(0) + 72 * p + 2 * (p >> 2) + 4 * comp + q));
+    }
+    // voff[g]: byte offset (inside a span) of the group that issue position g = i / 8 of the period loads next: absolute group
+    // 4 per + g + LA, 1 KiB per group; past the wave's last group the DMAs re-read that last group -- cache hits, no HBM traffic,
+    // and the vmcnt arithmetic stays as it is
     unsigned voff[4];
     const unsigned vmax = 16u * (unsigned)lane + 1024u * (unsigned)(4 * nper - 1); // offset of the wave's last group
 #pragma unroll
-    for (int g = 0; g < 4; ++g) voff[g] = min(16u * (unsigned)lane + 1024u * (unsigned)(g == 3 ? 3 : g + 4), vmax);
+    for (int g = 0; g < 4; ++g) voff[g] = min(16u * (unsigned)lane + 1024u * (unsigned)(g + LA), vmax);
     {
-        // groups 0, 1, 2 of the ring
+        // groups 0 .. LA - 1 of the ring
         unsigned v0 = 16u * (unsigned)lane;
-        mf_static_for<24>([&](auto ic) {
+        mf_static_for<8 * LA>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            mf_dma_issue<i / 8, i % 8>(ring, v0 + 1024u * (unsigned)(i / 8), sb[i % 8]);
+            mf_dma_issue<i % 8>(rs[i / 8], v0 + 1024u * (unsigned)(i / 8), sb[i % 8]);
         });
     }
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // group 0 has landed
-    uint4_t r = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd);
+    mf_wait_vm<8 * (LA - 1)>(); // group 0 has landed
+    uint4_t r = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lr[0]);
     for (int per = 0; per < nper; ++per) {
         oc.store = per >= WP;
         mf_static_for<P>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            constexpr int i1 = (i + 1) % P;
-            if constexpr (i1 % 8 == 0) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); // the next group has landed
-            const uint4_t rn = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lrd + (i1 / 8) * MF_GROUP_BYTES + 128 * (i1 % 8));
-            constexpr int g = (i / 8 + 3) % 4;
-            mf_dma_issue<g, i % 8>(ring, voff[g], sb[i % 8]);
-            // (next period's group of this slot; past the wave's last group the DMAs re-read that last group -- cache hits, no
-            // HBM traffic, and the vmcnt arithmetic stays as it is)
-            if constexpr (i % 8 == 7) voff[g] = min(voff[g] + 4096u, vmax);
+            constexpr int i1 = i + 1; // the step read ahead; i1 = 32: step 0 of the next period = group 4 of this one
+            // (MF_DMA_BURST = B: the 8 DMAs of a group go out B per step in its first 8 / B steps instead of one per step -- the
+            // shallow ring's worst-case lead is then 8 LA steps instead of 8 LA - 7)
+            constexpr int B = MF_DMA_BURST;
+            if constexpr (i1 % 8 == 0) mf_wait_vm<(B == 1 ? 8 * (LA - 2) + 7 : 8 * (LA - 1))>(); // the next group has landed
+            const uint4_t rn = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lr[(i1 / 8) % NG] + 128 * (i1 % 8));
+            constexpr int g = i / 8, d = i % 8;
+            if constexpr (d < 8 / B) {
+                mf_static_for<B>([&](auto bc) {
+                    constexpr int sp = B * d + decltype(bc)::value;
+                    mf_dma_issue<sp>(rs[(g + LA) % NG], voff[g], sb[sp]);
+                });
+                if constexpr (d == 8 / B - 1) voff[g] = min(voff[g] + 4096u, vmax); // next period's group of this issue position
+            }
             mf_front<NS, i>(st, k, fr, r);
             mf_stage<NS, 0, i>(st, k, oc, comp);
             r = rn;
         });
+        if constexpr (4 % NG != 0) { // the next period's group 0 is this period's group 4
+            const unsigned t = rs[0];
+            const __attribute__((address_space(3))) char *u = lr[0];
+#pragma unroll
+            for (int j = 0; j + 1 < NG; ++j) { rs[j] = rs[j + 1]; lr[j] = lr[j + 1]; }
+            rs[NG - 1] = t; lr[NG - 1] = u;
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // no DMA may outlive the workgroup's LDS allocation
+    mf_wait_vm<0>(); // no DMA may outlive the workgroup's LDS allocation
 }
 
-template <int NS, bool DMA = true> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, unsigned lds_addr)
+template <int NS, int NG = 0> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, unsigned lds_addr) // NG = 0: register ring
 {
+    // beside another kernel's waves (overlap mode) the matrix-core wave is the one the launch waits for: it issues first
+    if (a.mf_prio) __builtin_amdgcn_s_setprio(3);
     constexpr int L = NS;
     constexpr int P = mf_period<NS>();  // first-stage steps per period of the unrolled schedule
 #ifndef MF_DEPTH
@@ -423,8 +473,8 @@ template <int NS, bool DMA = true> __device__ __forceinline__ void mf_wave(const
     // {own half, received half} -> {first, second} half of the block: the I lane loaded the first half
     fr.sel_lo = comp ? 0x05040100u : 0x01000504u; fr.sel_hi = comp ? 0x07060302u : 0x03020706u;
     fr.ev_lo = 0u; fr.ev_hi = 0u;
-    if constexpr (DMA && mf_dma_applies(NS)) {
-        mf_loop_dma<NS>(a, st, k, oc, fr, lds_addr, wbase, S, nper, WP, lane, p, comp, q);
+    if constexpr (NG != 0 && mf_dma_applies(NS)) {
+        mf_loop_dma<NS, NG>(a, st, k, oc, fr, lds_addr, wbase, S, nper, WP, lane, p, comp, q);
         return;
     }
     uint4_t ld[D];
@@ -457,10 +507,10 @@ template <int NS, bool DMA = true> __device__ __forceinline__ void mf_wave(const
 // workgroups (head + tail pieces of every stream)
 __host__ __device__ constexpr int mf_block_threads(int) { return NT; }
 
-template <int L, bool PACK16> __global__ __launch_bounds__(mf_block_threads(L), mf_dma_applies(L) ? 1 : MF_WAVES) void decim_mfma_kernel(DecimArgs a)
+template <int L, bool PACK16, int NG> __global__ __launch_bounds__(mf_block_threads(L), mf_dma_applies(L) ? 1 : MF_WAVES) void decim_mfma_kernel(DecimArgs a)
 {
     // the VALU pieces' stage buffers, or (matrix-core workgroups of the long cascades) the four waves' LDS-DMA rings
-    constexpr int LDSDW = mf_dma_applies(L) && 4 * MF_WAVE_RING / 4 > DecimLds<L, 2, PACK16>::dwords ? 4 * MF_WAVE_RING / 4 : DecimLds<L, 2, PACK16>::dwords;
+    constexpr int LDSDW = mf_dma_applies(L) && mf_wave_ring(NG) > DecimLds<L, 2, PACK16>::dwords ? mf_wave_ring(NG) : DecimLds<L, 2, PACK16>::dwords; // (4 waves x ring bytes / 4)
     __shared__ __attribute__((aligned(16))) int lds[LDSDW];
     // The matrix-core workgroups come FIRST in the grid: the dispatcher deals the first workgroups of a launch across
     // the empty CUs, and with one wave per SIMD (plan_decimate_mfma) the launch takes as long as its fullest CU: a CU
@@ -493,7 +543,7 @@ template <int L, bool PACK16> __global__ __launch_bounds__(mf_block_threads(L), 
     }
     const int gw = __builtin_amdgcn_readfirstlane(bx * 4 + (int)(threadIdx.x >> 6));
     if (gw >= a.nstreams * a.mf_wps) return;
-    mf_wave<L>(a, gw, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds);
+    mf_wave<L, NG>(a, gw, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds);
 }
 
 // ---- fused Rx launch: the decimator of THIS call and the CM256 encoder of the frames the PREVIOUS call completed, in one grid.
@@ -562,7 +612,7 @@ template <int L, bool PACK16> __global__ __launch_bounds__(NT, MF_FUSED_WPE) voi
     }
     const int gw = __builtin_amdgcn_readfirstlane(bx * 4 + (int)(threadIdx.x >> 6));
     if (gw >= a.nstreams * a.mf_wps) return;
-    mf_wave<L, false>(a, gw, 0u);
+    mf_wave<L, 0>(a, gw, 0u);
 }
 
 template <int L> hipError_t launch_fused(bool pack16, const DecimArgs &a, const Enc128Args &e, unsigned *roles, unsigned tag, hipStream_t stream)
@@ -581,8 +631,16 @@ template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream
     const int nleg = a.mf_piece_wgs > 0 ? a.mf_piece_wgs : a.nstreams * a.mf_npieces;
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
     const dim3 grid(nleg + nmf), block(mf_block_threads(L));
-    if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((decim_mfma_kernel<L, false>), grid, block, 0, stream, a);
+    // ring depth: only the LDS-DMA kernel (decimate16) has one, and only it comes in both depths (DecimArgs::mf_ring)
+    if constexpr (mf_dma_applies(L)) {
+        if (a.mf_ring == 3) {
+            if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true, 3>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((decim_mfma_kernel<L, false, 3>), grid, block, 0, stream, a);
+            return hipGetLastError();
+        }
+    }
+    if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true, 4>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((decim_mfma_kernel<L, false, 4>), grid, block, 0, stream, a);
     return hipGetLastError();
 }
 

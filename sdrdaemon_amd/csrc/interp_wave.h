@@ -34,6 +34,27 @@ static_assert(W0STR % 64 == 32 && W0STR >= W0HIST + 64 * WG, "stage-0 plane stri
 
 typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
 
+// Q-plane swizzle of the stage buffers s >= 1 (round 5 experiment, OFF by default: WSWZ = 0).  A stage writes its 8 outputs per lane
+// as two ds_write_b128; the lanes of an I / Q pair write the same positions of their planes, and the planes lie WSTR = 288 = 0
+// (mod 32) dwords apart -- which the ds_read_b128 window reads want (I / Q lanes of a 16-lane service group then hit distinct
+// 4-bank columns of the 64 banks), but a ds_write_b128 is serviced in groups of 8 lanes over 32 banks: the I and the Q lane of
+// every pair collide, 2-way, on every write.  That is ALL of the kernel's bank conflicts (SQ_LDS_BANK_CONFLICT 19.3 M of
+// SQ_LDS_IDX_ACTIVE 68.7 M cycles per 2^28 outputs = 28 %).  WSWZ = 4 stores entry e of the Q plane at position e ^ 4 (the halves
+// of every aligned 8-dword group trade places: the Q lane's first ds_write_b128 goes to the upper half while the I lane's goes to
+// the lower one; the windows are read as whole 4-dword groups from two lane-constant bases): the write conflicts are gone
+// (-10.7 M cycles), but the window groups of ODD index now collide between I and Q lanes on the read side (8.6 M conflict cycles
+// left, 14.8 %), and the launch time does not move: 0.2411 / 0.2411 ms against 0.2398 / 0.2419 ms, trace average 243.8 against
+// 240.7 us (profiles/r05_k5w_swizzle.txt) -- the LDS array is busy 40 % of the launch, conflicts included, and is not what the
+// kernel waits for; the swizzle also costs 8 VGPRs (interpolate8 loses its fifth wave per SIMD: +1.3 %).  A swizzle that is
+// conflict-free on both sides exists (brute force over all half-swaps keyed by plane and index bits 3-5: 16 solutions), but every
+// one of them needs bit 5 of the entry index, i.e. per-read address arithmetic instead of immediates (3-4 VALU per ds_read_b128 on
+// a kernel whose VALU port is the busier resource).  Left in as the A / B partner: make EXTRA=-DWSWZ=4.
+#ifndef WSWZ
+#define WSWZ 0
+#endif
+// position of entry `idx` (a multiple of 4 plus x) in plane `comp`: idx ^ (comp ? WSWZ : 0)
+__device__ __forceinline__ int wswz(int idx, int comp) { return idx ^ (comp ? WSWZ : 0); }
+
 template <int NS_> struct WGeo {
     static constexpr int NS = NS_;
     static constexpr int base(int s) { return s == 0 ? 0 : 2 * W0STR + (s - 1) * 2 * WSTR; }
@@ -102,8 +123,8 @@ template <class G, bool FULL> __device__ __forceinline__ void wstage0(int *lds, 
     o[0] = (int)(short)(W[8] & 0xffffu); o[2] = (int)W[8] >> 16; o[4] = (int)(short)(W[9] & 0xffffu); o[6] = (int)W[9] >> 16;
     o[1] = acc[0] >> 13; o[3] = acc[1] >> 13; o[5] = acc[2] >> 13; o[7] = acc[3] >> 13;
     int *nx = lds + G::base(1) + comp * WSTR + HIST + 2 * m0;
-    *reinterpret_cast<int4_t *>(nx) = (int4_t){o[0], o[1], o[2], o[3]};
-    *reinterpret_cast<int4_t *>(nx + 4) = (int4_t){o[4], o[5], o[6], o[7]};
+    *reinterpret_cast<int4_t *>(nx + wswz(0, comp)) = (int4_t){o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<int4_t *>(nx + wswz(4, comp)) = (int4_t){o[4], o[5], o[6], o[7]};
 }
 
 // a middle stage (1 <= S < NS - 1): `valid` inputs at in_off of its buffer -> 2 * valid entries at the start of the next buffer
@@ -112,11 +133,15 @@ template <class G, int S, bool FULL> __device__ __forceinline__ void wstage(int 
     constexpr int O = stage_order(S), K = O / 4, S2 = O / 2, R = 4;
     const int j = lane >> 1, comp = lane & 1, m0 = j * R;
     if (!FULL && m0 >= valid) return;
-    const int *pl = lds + G::base(S) + comp * WSTR + HIST + in_off + m0 - S2; // window x <-> u[m0 - O/2 + x]
+    // window x <-> u[m0 - O/2 + x]; the window's 4-dword groups alternate between the two swizzled bases (HIST + in_off - S2 is a
+    // multiple of 8, so the group parity is that of j + x / 4)
+    static_assert(S2 % 8 == 0 && HIST % 8 == 0 && WB % 8 == 0, "aligned 8-dword groups");
+    const int *plane = lds + G::base(S) + comp * WSTR + HIST + in_off - S2;
+    const int *plE = plane + wswz(m0, comp), *plO = plane + (wswz(m0 + 4, comp) - 4);
     int w[R + S2];
 #pragma unroll
     for (int x = 0; x < R + S2; x += 4) {
-        const int4_t v = *reinterpret_cast<const int4_t *>(pl + x);
+        const int4_t v = *reinterpret_cast<const int4_t *>(((x >> 2) & 1 ? plO : plE) + x);
         w[x] = v.x; w[x + 1] = v.y; w[x + 2] = v.z; w[x + 3] = v.w;
     }
 #pragma unroll
@@ -128,8 +153,8 @@ template <class G, int S, bool FULL> __device__ __forceinline__ void wstage(int 
         o[2 * r + 1] = acc >> 13;
     }
     int *nx = lds + G::base(S + 1) + comp * WSTR + HIST + 2 * m0;
-    *reinterpret_cast<int4_t *>(nx) = (int4_t){o[0], o[1], o[2], o[3]};
-    *reinterpret_cast<int4_t *>(nx + 4) = (int4_t){o[4], o[5], o[6], o[7]};
+    *reinterpret_cast<int4_t *>(nx + wswz(0, comp)) = (int4_t){o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<int4_t *>(nx + wswz(4, comp)) = (int4_t){o[4], o[5], o[6], o[7]};
 }
 
 // the last stage: both components per lane, taps x 8 (the int16 result is the accumulator's high half), 2 x 16-byte stores
@@ -141,11 +166,12 @@ template <class G, int S, bool FULL> __device__ __forceinline__ void wstage_last
     int ev[2][R], od[2][R];
 #pragma unroll
     for (int comp = 0; comp < 2; ++comp) {
-        const int *pl = lds + G::base(S) + comp * WSTR + HIST + in_off + m0 - S2;
+        const int *plane = lds + G::base(S) + comp * WSTR + HIST + in_off - S2;
+        const int *plE = plane + wswz(m0, comp), *plO = plane + (wswz(m0 + 4, comp) - 4);
         int w[R + S2];
 #pragma unroll
         for (int x = 0; x < R + S2; x += 4) {
-            const int4_t v = *reinterpret_cast<const int4_t *>(pl + x);
+            const int4_t v = *reinterpret_cast<const int4_t *>(((x >> 2) & 1 ? plO : plE) + x);
             w[x] = v.x; w[x + 1] = v.y; w[x + 2] = v.z; w[x + 3] = v.w;
         }
 #pragma unroll
@@ -191,10 +217,10 @@ template <class G, int S, bool FULL> __device__ __forceinline__ void wstage_last
 template <class G, int S> __device__ __forceinline__ void whist(int *lds, int lane, int n)
 {
     int *pl = lds + G::base(S) + (lane >> 5) * WSTR;
-    const int e = lane & 31;
-    const int v = pl[n + e]; // = fresh entry n - 32 + e (or history entry n + e when n < 32)
+    const int e = lane & 31, q = lane >> 5;
+    const int v = pl[wswz(n + e, q)]; // = fresh entry n - 32 + e (or history entry n + e when n < 32)
     wave_sync();
-    pl[e] = v;
+    pl[wswz(e, q)] = v;
 }
 
 // FULL: a whole block with its stores (valid = 128 per stage invocation, 256 in the last stage): every guard is a compile-time
@@ -236,13 +262,13 @@ template <class G, int S = 0> __device__ __forceinline__ void wstate_fetch(int (
 template <class G, int S = 0> __device__ __forceinline__ void wstate_put(int *lds, int lane, const int (&sv)[G::NS])
 {
     if constexpr (S == 0) reinterpret_cast<short *>(lds + (lane >> 5) * W0STR)[lane & 31] = (short)sv[S];
-    else lds[G::base(S) + (lane >> 5) * WSTR + (lane & 31)] = sv[S];
+    else lds[G::base(S) + (lane >> 5) * WSTR + wswz(lane & 31, lane >> 5)] = sv[S];
     if constexpr (S + 1 < G::NS) wstate_put<G, S + 1>(lds, lane, sv);
 }
 template <class G, int S = 0> __device__ __forceinline__ void wstate_store(const int *lds, int lane, int32_t *st)
 {
     if constexpr (S == 0) st[lane] = (int)reinterpret_cast<const short *>(lds + (lane >> 5) * W0STR)[lane & 31];
-    else st[S * 2 * INT_HIST + lane] = lds[G::base(S) + (lane >> 5) * WSTR + (lane & 31)];
+    else st[S * 2 * INT_HIST + lane] = lds[G::base(S) + (lane >> 5) * WSTR + wswz(lane & 31, lane >> 5)];
     if constexpr (S + 1 < G::NS) wstate_store<G, S + 1>(lds, lane, st);
 }
 

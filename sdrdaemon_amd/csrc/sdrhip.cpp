@@ -93,6 +93,7 @@ static void ctx_free(sdrhip_ctx *c);
 static void drop_kernel_events(sdrhip_ctx *c)
 {
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (int k = 0; k < 4; ++k) {
         for (auto &pr : c->kev[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
         c->kev[k].clear();
@@ -119,7 +120,7 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
         // sdrhip_ctx_set_option()
         static const char *const keys[][2] = {{"SDRHIP_DECIM_PATH", "decim_path"}, {"SDRHIP_MFMA_SPAN", "mfma_span"}, {"SDRHIP_MFMA_MIN", "mfma_min"},
                                               {"SDRHIP_INTERP_PATH", "interp_path"}, {"SDRHIP_INTERP_SPAN", "interp_span"}, {"SDRHIP_RX_FUSED", "rx_fused"},
-                                              {"SDRHIP_DEC_PATH", "dec_path"}};
+                                              {"SDRHIP_DEC_PATH", "dec_path"}, {"SDRHIP_MFMA_RING", "mfma_ring"}, {"SDRHIP_TX_OVERLAP", "tx_overlap"}};
         for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); ++i)
             if (const char *v = getenv(keys[i][0])) (void)sdrhip_ctx_set_option(c, keys[i][1], v);
     }
@@ -154,6 +155,20 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
 }
 
 namespace sdrhip {
+int ctx_stream2(sdrhip_ctx *c, hipStream_t *out)
+{
+    if (!c->stream2) {
+        // lowest priority: when both streams have workgroups to place, the first stream's (the long kernel) go first
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = 0;
+        if (hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo) != hipSuccess) {
+            c->stream2 = nullptr;
+            return fail(SDRHIP_EDEVICE, "hipStreamCreate (second stream)");
+        }
+    }
+    *out = c->stream2;
+    return SDRHIP_OK;
+}
 void ctx_retain(sdrhip_ctx *c) { c->refs.fetch_add(1); }
 void ctx_release(sdrhip_ctx *c)
 {
@@ -191,7 +206,10 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
     } else if (k == "mfma_span" && isnum) c->opt.mfma_span = (size_t)num;
     else if (k == "mfma_min" && isnum) c->opt.mfma_min = (size_t)num;
     else if (k == "interp_span" && isnum) c->opt.interp_span = (size_t)num;
-    else if (k == "rx_fused" && isnum) c->opt.rx_fused = (int)num;
+    else if (k == "rx_fused" && isnum && num <= 3) c->opt.rx_fused = (int)num;
+    else if (k == "rx_fused" && v == "overlap") c->opt.rx_fused = 3;
+    else if (k == "mfma_ring" && isnum && (num == 3 || num == 4)) c->opt.mfma_ring = (int)num;
+    else if (k == "tx_overlap" && isnum && num <= 1) c->opt.tx_overlap = (int)num;
     else if (k == "dec_path") {
         if (v == "syndrome") c->opt.dec_syndrome = 1;
         else if (v == "dense") c->opt.dec_syndrome = 0;
@@ -233,6 +251,7 @@ static void sdrhip::ctx_free(sdrhip_ctx *c)
     c->dec_plan.release();
     c->pin.release();
     c->zin.release(); c->zout.release();
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
@@ -243,6 +262,7 @@ extern "C" int sdrhip_ctx_synchronize(sdrhip_ctx *c)
     if (!c) return fail(SDRHIP_EINVAL, "ctx is NULL");
     sdrhip::CtxLock lock_(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
     return SDRHIP_OK;
 }
 
@@ -277,6 +297,7 @@ extern "C" int sdrhip_ctx_kernel_timing_read(sdrhip_ctx *c, int cls, double *tot
     if (!c || cls < 0 || cls > 3 || !total_ms || !launches) return fail(SDRHIP_EINVAL, "kernel_timing_read: bad argument");
     sdrhip::CtxLock lock_(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
     double sum = 0;
     unsigned n = 0;
     for (auto &pr : c->kev[cls]) {
@@ -366,7 +387,7 @@ namespace sdrhip {
 // device-pointer core shared with the fused Rx pipe; frame_* = 0 for plain output
 int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in,
                     size_t n_in, size_t in_stride, int16_t *out, size_t out_stride, size_t *n_out, int frame_mode,
-                    int frame_blocks, uint64_t frame_sample_base, const RxMeta *meta, const Enc128Args *fuse, bool *fused)
+                    int frame_blocks, uint64_t frame_sample_base, const RxMeta *meta, const Enc128Args *fuse, bool *fused, bool coresident)
 {
     if (fused) *fused = false;
     sdrhip_ctx *c = d->ctx;
@@ -422,6 +443,8 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     if (!frame_mode && env.decim_path != DECIM_PATH_VALU && (env.decim_path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= mfma_min_samples(env, (int)L)))
         use_mfma = plan_decimate_mfma((int)L, fcpos, a.n_used, d->nstreams, env.mfma_span, c->n_cu, &a);
     a.mf_dump = c->decim_dump;
+    a.mf_ring = coresident ? 3 : env.mfma_ring;
+    a.mf_prio = coresident ? 1 : 0;
     hipError_t e;
     {
         KTimer kt(c, SDRHIP_K_DECIMATE);

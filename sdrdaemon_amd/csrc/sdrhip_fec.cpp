@@ -16,12 +16,12 @@ namespace sdrhip {
 // below this many recovery blocks the generic kernel (rows x 128 products) is cheaper than a full
 // 32-row Karatsuba tile (13.7 k lane-ops per column vs 36 k x rows / 32): ENC128_MIN_ROWS, sdrhip_internal.h
 
-int fec_encode128_launch(sdrhip_ctx *c, const Enc128Args &k)
+int fec_encode128_launch(sdrhip_ctx *c, const Enc128Args &k, hipStream_t on)
 {
     hipError_t e;
     {
-        KTimer kt(c, SDRHIP_K_FEC_ENCODE);
-        e = launch_gf_encode128(k, c->stream);
+        KTimer kt(c, SDRHIP_K_FEC_ENCODE, on);
+        e = launch_gf_encode128(k, on ? on : c->stream);
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec encode launch: %s", hipGetErrorString(e));
     return SDRHIP_OK;
@@ -75,16 +75,22 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
 // erasure patterns in a batch.  indices: optional HOST array (nframes x 128 block indices in arrival order); NULL = the
 // kernels read header.blockIndex of the super blocks themselves (:147).
 int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
-                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out)
+                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out, const DecodeSide *side)
 {
+    // (side: a pipelined Tx pipe decodes on the context's second stream with work buffers of its own, so that the context's
+    // shared ones stay free for whatever runs on the first stream meanwhile)
+    hipStream_t st = side ? side->stream : c->stream;
+    DevBuf &planbuf = side ? *side->plan : c->dec_plan;
+    DevBuf &idxbuf = side ? *side->idx : c->aux;
+    PinnedBuf &pinbuf = side ? *side->pin : c->pin;
     if (nframes == 0) return SDRHIP_OK;
     if (nframes > 0x3fffffffu) return fail(SDRHIP_EINVAL, "fec decode: too many frames in one call");
     // (the dense path's scatter pass puts the frame index in gridDim.y: 65535 at most; the default syndrome path has no such pass)
     if (!c->opt.dec_syndrome && nframes > 65535) return fail(SDRHIP_EINVAL, "fec decode (dec_path = dense): at most 65535 frames per call");
     int rc;
-    if ((rc = c->dec_plan.reserve(DecodeBuffers::bytes(nframes)))) return rc;
+    if ((rc = planbuf.reserve(DecodeBuffers::bytes(nframes)))) return rc;
     DecodeBuffers d;
-    uint8_t *base = c->dec_plan.as<uint8_t>();
+    uint8_t *base = planbuf.as<uint8_t>();
     d.coef = base; base += nframes * (size_t)128 * 128;
     d.pmap = reinterpret_cast<int16_t *>(base); base += nframes * 128 * sizeof(int16_t);
     d.zmap = reinterpret_cast<int16_t *>(base); base += nframes * 128 * sizeof(int16_t);
@@ -97,18 +103,18 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
     const uint8_t *idx_dev = nullptr;
     if (indices) {
         const size_t nb = nframes * (size_t)SDRHIP_NB_ORIGINAL;
-        if ((rc = c->pin.reserve(nb))) return rc;
-        if ((rc = c->aux.reserve(nb))) return rc;
-        memcpy(c->pin.p, indices, nb);
-        HIP_TRY(hipMemcpyAsync(c->aux.p, c->pin.p, nb, hipMemcpyHostToDevice, c->stream));
-        c->pin.mark(c->stream);
-        idx_dev = c->aux.as<uint8_t>();
+        if ((rc = pinbuf.reserve(nb))) return rc;
+        if ((rc = idxbuf.reserve(nb))) return rc;
+        memcpy(pinbuf.p, indices, nb);
+        HIP_TRY(hipMemcpyAsync(idxbuf.p, pinbuf.p, nb, hipMemcpyHostToDevice, st));
+        pinbuf.mark(st);
+        idx_dev = idxbuf.as<uint8_t>();
     }
     hipError_t e;
     {
-        KTimer kt(c, SDRHIP_K_FEC_DECODE);
+        KTimer kt(c, SDRHIP_K_FEC_DECODE, side ? st : nullptr);
         e = launch_fec_decode_device_plan(d, rx, rx_frame_bytes, idx_dev, c->gf_explog, c->gf_tab, (int)nframes, payload_out,
-                                          payload_frame_bytes, block0_out, c->opt.dec_max_rows, c->opt.dec_strict, c->dec_stats, c->stream);
+                                          payload_frame_bytes, block0_out, c->opt.dec_max_rows, c->opt.dec_strict, c->dec_stats, st);
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec decode launch: %s", hipGetErrorString(e));
     return SDRHIP_OK;

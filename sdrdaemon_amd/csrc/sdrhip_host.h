@@ -72,7 +72,10 @@ inline unsigned decimated_sample_size(unsigned log2decim, unsigned ss)
 // device-pointer cores (no argument validation, no staging)
 int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sampleSize, const int16_t *in, size_t n_in,
                     size_t in_stride, int16_t *out, size_t out_stride, size_t *n_out, int frame_mode, int frame_blocks,
-                    uint64_t frame_sample_base, const RxMeta *meta = nullptr, const Enc128Args *fuse = nullptr, bool *fused = nullptr);
+                    uint64_t frame_sample_base, const RxMeta *meta = nullptr, const Enc128Args *fuse = nullptr, bool *fused = nullptr,
+                    bool coresident = false); // coresident: another kernel's workgroups share the CUs (ring depth 3, raised wave priority)
+// the context's second stream (created on first use; non-blocking, so that it never synchronises with a NULL caller stream)
+int ctx_stream2(sdrhip_ctx *c, hipStream_t *out);
 bool decimate_mfma_applies(const sdrhip_decimators *d, int log2decim, int fcpos, size_t n_in);
 int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *in, size_t n_in, size_t in_stride, int16_t *out,
                        size_t out_stride, size_t *n_out);
@@ -91,10 +94,15 @@ inline bool fec_encode_fuses_framing(int nb_fec) { return nb_fec >= sdrhip::ENC1
 int fec_encode_device(sdrhip_ctx *ctx, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
                       size_t rec_frame_bytes, const int32_t *frame_list_dev = nullptr, int ngroups = 0, const EncodeLin *lin = nullptr);
 // the structured 128-original encoder on prepared arguments (the Rx pipe's deferred encode)
-int fec_encode128_launch(sdrhip_ctx *ctx, const Enc128Args &k);
+int fec_encode128_launch(sdrhip_ctx *ctx, const Enc128Args &k, hipStream_t on = nullptr); // on: another stream than the context's
 // rx on the device, indices on the host; payload_out / block0_out on the device
+struct DecodeSide { // decode on another stream than the context's, with the caller's own work buffers
+    hipStream_t stream;
+    DevBuf *plan, *idx;
+    PinnedBuf *pin;
+};
 int fec_decode_device(sdrhip_ctx *ctx, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
-                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out);
+                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out, const DecodeSide *side = nullptr);
 
 } // namespace sdrhip
 
@@ -109,7 +117,11 @@ struct CtxOptions {
     size_t mfma_min = (size_t)1 << 22;     // smallest call (samples over all streams, decimate4 / 8) the matrix cores take in auto mode
     int interp_wave = 1;                   // interpolate4 .. 64: K5w, the barrier-free wave-private pipeline (interp_wave.h); 0 = K5
     size_t interp_span = 0;
-    int rx_fused = 1;                      // pipelined Rx pipe: encoder in the decimator's launch (0 = separate launches)
+    int mfma_ring = 4;                     // LDS-DMA ring depth of the decimate16 matrix-core kernel (3 or 4 groups; overlap mode always runs 3)
+    // pipelined Rx pipe, where the encoder of the previous call's frames runs: 0 = its own launch behind the decimator, 1 = inside the
+    // decimator's launch (rx_fused_kernel), 3 = its own launch on the context's SECOND stream, beside the decimator ("overlap")
+    int rx_fused = 1;
+    int tx_overlap = 1;                    // pipelined Tx pipe: 1 = decode of this batch on the second stream beside the interpolator of the previous one, 0 = one stream
     int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)
     int dec_strict = 0;                    // batched decode delivers only what the reference's copy-back loop delivers (SDRdaemonFECBuffer.cpp:204-211)
     int dec_max_rows = 128;                // upper bound of the recovery blocks a received frame can have used (the sender's fecblk)
@@ -131,6 +143,7 @@ struct sdrhip_ctx {
     int n_cu = 256;                          // hipDeviceProp_t::multiProcessorCount (the planners size their grids from it)
     sdrhip::CtxOptions opt;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;           // the library's own second stream (created on first use: overlap modes of the pipes)
     std::atomic<int> refs{0}; // handles created on this context (they keep it alive)
     std::atomic<bool> dying{false}; // sdrhip_ctx_destroy was called while handles were still alive
     sdrhip::DevBuf in, out, aux, aux3;       // staging for SDRHIP_MEM_HOST calls and FEC work areas
@@ -163,7 +176,8 @@ struct KTimer {
     sdrhip_ctx *c;
     int cls;
     hipEvent_t e1 = nullptr;
-    KTimer(sdrhip_ctx *ctx, int kernel_class) : c(ctx), cls(kernel_class)
+    hipStream_t st;
+    KTimer(sdrhip_ctx *ctx, int kernel_class, hipStream_t on = nullptr) : c(ctx), cls(kernel_class), st(on ? on : ctx->stream)
     {
         if (!c->ktime_on) return;
         // (an event pair around a launch costs the stream ~2.5 us: timing every launch of a two-launch step took 3 % off the step)
@@ -171,12 +185,12 @@ struct KTimer {
         hipEvent_t e0 = nullptr;
         if (hipEventCreate(&e0) != hipSuccess) return;
         if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); e1 = nullptr; return; }
-        (void)hipEventRecord(e0, c->stream);
+        (void)hipEventRecord(e0, st);
         c->kev[cls].push_back(std::make_pair(e0, e1));
     }
     ~KTimer()
     {
-        if (e1) (void)hipEventRecord(e1, c->stream);
+        if (e1) (void)hipEventRecord(e1, st);
     }
 };
 } // namespace sdrhip

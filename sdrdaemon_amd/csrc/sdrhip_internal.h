@@ -68,6 +68,8 @@ struct DecimArgs {
     // pieces each (they start with the launch, on the CUs the matrix-core workgroups leave free), every other one a single piece
     int mf_piece_wgs, mf_piece_early, mf_piece_share;
     unsigned *mf_dump;   // >= 1 KiB of device memory that swallows the stores of the warm-up period
+    int mf_ring;         // LDS-DMA ring depth of the decimate16 kernel in groups: 4 (147 KiB per workgroup), 3 (108 KiB: room for another kernel)
+    int mf_prio;         // 1: the matrix-core waves raise their issue priority (they share their SIMDs with another kernel's waves)
 };
 
 // MetaDataFEC of the fi-th frame a call starts (UDPSinkFEC.cpp:90-115: the reference takes gettimeofday() when it opens a

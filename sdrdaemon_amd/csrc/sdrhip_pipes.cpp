@@ -157,6 +157,10 @@ struct sdrhip_rx {
         size_t slot0 = 0;           // window position inside `work` (overlap check of the sliding window), SIZE_MAX = other area
     } late;
     DevBuf old_work;          // the previous frame area after a re-allocation, kept while `late` points into it
+    // overlap mode (option rx_fused = 3): the waiting encode runs on the context's second stream beside the next call's decimator.
+    // ev_framed: recorded on the first stream when a call has written everything its deferred encode reads (decimator + K2);
+    // ev_enc: recorded on the second stream behind the encode, the first stream waits for it before the frames are delivered
+    hipEvent_t ev_framed = nullptr, ev_enc = nullptr;
     // ---- asynchronous host-pointer entry (sdrhip_rx_submit / sdrhip_rx_collect): a ring of batches
     struct Batch {
         PinnedBuf in;             // the submitted blocks, appended: [block][stream][n] (unless the caller's memory is pinned by us)
@@ -209,7 +213,20 @@ static int rx_settle(sdrhip_rx *rx)
 {
     if (!rx->late.encode) return SDRHIP_OK;
     rx->late.encode = false;
-    return fec_encode128_launch(rx->ctx, rx->late.k);
+    sdrhip_ctx *c = rx->ctx;
+    if (c->opt.rx_fused != 3 || !rx->ev_framed) return fec_encode128_launch(c, rx->late.k);
+    // overlap mode: the encode goes to the second stream -- behind everything the call that left it had enqueued (ev_framed), beside
+    // whatever the first stream runs now (the decimator of the current call, enqueued just before) -- and the first stream picks
+    // up behind it: the frames are delivered, and the buffers reused, in first-stream order
+    hipStream_t s2 = nullptr;
+    int rc = ctx_stream2(c, &s2);
+    if (rc) return rc;
+    if (!rx->ev_enc) HIP_TRY(hipEventCreateWithFlags(&rx->ev_enc, hipEventDisableTiming));
+    HIP_TRY(hipStreamWaitEvent(s2, rx->ev_framed, 0));
+    if ((rc = fec_encode128_launch(c, rx->late.k, s2))) return rc;
+    HIP_TRY(hipEventRecord(rx->ev_enc, s2));
+    HIP_TRY(hipStreamWaitEvent(c->stream, rx->ev_enc, 0));
+    return SDRHIP_OK;
 }
 
 extern "C" int sdrhip_rx_set_pipelined(sdrhip_rx *rx, int on)
@@ -267,6 +284,8 @@ extern "C" void sdrhip_rx_destroy(sdrhip_rx *rx)
     rx->lin[0].release();
     rx->lin[1].release();
     rx->flist.release();
+    if (rx->ev_framed) (void)hipEventDestroy(rx->ev_framed);
+    if (rx->ev_enc) (void)hipEventDestroy(rx->ev_enc);
     for (auto &b : rx->abatch) {
         if (b.done) { (void)hipEventSynchronize(b.done); (void)hipEventDestroy(b.done); }
         b.in.release(); b.din.release(); b.out.release();
@@ -459,7 +478,10 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     memset(&fa, 0, sizeof(fa));
     const bool structured = R >= ENC128_MIN_ROWS && frame_bytes % 4 == 0; // gf_encode128_kernel serves this setting
     const bool filterless = L == 0 || (rx->cfg.fcpos != SDRHIP_FC_CEN && L <= 2); // Decimators.cpp:22-91,127-170: no cascade kernel
-    const Enc128Args *fuse = rx->late.encode && c->opt.rx_fused ? &rx->late.k : nullptr;
+    const Enc128Args *fuse = rx->late.encode && (c->opt.rx_fused == 1 || c->opt.rx_fused == 2) ? &rx->late.k : nullptr;
+    // overlap mode: the waiting encode will run on the second stream BESIDE this call's decimator (rx_settle below), which therefore
+    // leaves room on its CUs (ring depth 3) and raises its waves' priority
+    const bool coresident = rx->late.encode && c->opt.rx_fused == 3 && rx->ev_framed;
     bool fused = false;
     if (filterless || decimate_mfma_applies(rx->dec, L, rx->cfg.fcpos, n_in)) {
         // ---- decimate in stream order, then K2 lays the samples out as super blocks (+ meta blocks and headers)
@@ -468,7 +490,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         DevBuf &lin = rx->lin[rx->lin_sel];
         if (lin.cap < (size_t)S * lstride * 4 + 16 && rx->late.encode) { if ((rc = rx_settle(rx))) return rc; fuse = nullptr; HIP_TRY(hipStreamSynchronize(c->stream)); }
         if ((rc = lin.reserve((size_t)S * lstride * 4 + 16))) return rc;
-        rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, lin.as<int16_t>(), lstride, &n_out, 0, 0, 0, nullptr, fuse, &fused);
+        rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, lin.as<int16_t>(), lstride, &n_out, 0, 0, 0, nullptr, fuse, &fused, coresident);
         if (rc) return rc;
         if (fused) rx->late.encode = false;
         // the frames that lie entirely inside this call's samples are laid out by the encoder (fused copy); K2 does
@@ -560,6 +582,10 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         }
         rx->late.have = done > 0;
         rx->late.encode = encode_later;
+        if (encode_later && c->opt.rx_fused == 3) { // (everything the deferred encode reads has been enqueued on the first stream by now)
+            if (!rx->ev_framed) HIP_TRY(hipEventCreateWithFlags(&rx->ev_framed, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(rx->ev_framed, c->stream));
+        }
         rx->late.k = k;
         rx->late.base = work; rx->late.stride = stream_bytes; rx->late.frames = done; rx->late.frame_bytes = frame_bytes;
         rx->late.slot0 = rx->base_slot;
@@ -788,7 +814,34 @@ struct sdrhip_tx {
     int nstreams;
     int log2interp;
     sdrhip_interpolators *itp;
-    DevBuf rxbuf, payload, outbuf;
+    DevBuf rxbuf, payload[2], outbuf;
+    // ---- pipelined mode (sdrhip_tx_set_pipelined): a call decodes ITS batch into payload[psel] -- on the context's second stream,
+    // with work buffers of its own -- while the first stream interpolates the batch the PREVIOUS call decoded (payload[psel ^ 1]);
+    // the samples are delivered one call late, like SDRdaemonFECBuffer delivers a frame when the next one begins (.cpp:133-139)
+    int pipelined = 0;
+    int psel = 0;
+    struct Late {
+        bool have = false;
+        size_t n_payload = 0, pstride = 0;
+        int log2interp = 0; // the factor in force when the batch was handed in
+    } late;
+    DevBuf plan_own, idx_own;
+    PinnedBuf pin_own;
+    hipEvent_t ev_in = nullptr;              // first stream: the caller's device rx buffer is ready
+    hipEvent_t ev_dec = nullptr;             // second stream: the waiting batch is decoded
+    hipEvent_t ev_itp[2] = {nullptr, nullptr}; // first stream: the interpolator has read payload[i]
+    bool itp_pending[2] = {false, false};
+    // ---- asynchronous host-pointer entry (sdrhip_tx_submit / sdrhip_tx_collect): a ring of batches of received frames
+    struct ABatch {
+        PinnedBuf in;             // the batch's received super blocks [stream][frame][128][512] (staged; sdrhip_host_alloc memory is used in place)
+        DevBuf din, dout, db0;    // ... on the device; its samples [stream][dos]; its meta blocks [stream * nframes][508]
+        PinnedBuf out;            // samples, then meta blocks, downloaded
+        hipEvent_t done = nullptr;
+        size_t nframes = 0, n_res = 0, dos = 0;
+        int state = 0;            // 0 free, 2 in flight
+    };
+    std::vector<ABatch> abatch;
+    size_t a_head = 0, a_tail = 0;
 };
 
 extern "C" int sdrhip_tx_create(sdrhip_ctx *ctx, int nstreams, int log2interp, sdrhip_tx **out)
@@ -806,7 +859,8 @@ extern "C" int sdrhip_tx_create(sdrhip_ctx *ctx, int nstreams, int log2interp, s
 
 // Upsampler::configure (Upsampler.cpp:31-50), applied between two batches like sdrdaemontx does with a control message
 // (sdrdaemontx.cpp:381): the six interpolator instances are shared by every interpolateN entry point
-// (Interpolators.h:47-52), so their histories carry over.
+// (Interpolators.h:47-52), so their histories carry over.  (Pipelined mode: a batch that waits for delivery keeps the factor
+// it was handed in with.)
 extern "C" int sdrhip_tx_reconfigure(sdrhip_tx *tx, int log2interp)
 {
     if (!tx) return fail(SDRHIP_EINVAL, "tx is NULL");
@@ -819,9 +873,116 @@ extern "C" int sdrhip_tx_reconfigure(sdrhip_tx *tx, int log2interp)
 extern "C" void sdrhip_tx_destroy(sdrhip_tx *tx)
 {
     if (!tx) return;
-    sdrhip_interpolators_destroy(tx->itp);
-    tx->rxbuf.release(); tx->payload.release(); tx->outbuf.release();
+    (void)hipSetDevice(tx->ctx->device);
+    if (tx->ctx->stream2) (void)hipStreamSynchronize(tx->ctx->stream2); // (a decode of the pipelined mode may still run there)
+    sdrhip_interpolators_destroy(tx->itp); // (synchronises the first stream)
+    tx->rxbuf.release(); tx->payload[0].release(); tx->payload[1].release(); tx->outbuf.release();
+    tx->plan_own.release(); tx->idx_own.release(); tx->pin_own.release();
+    for (auto &b : tx->abatch) {
+        if (b.done) { (void)hipEventSynchronize(b.done); (void)hipEventDestroy(b.done); }
+        b.in.release(); b.din.release(); b.dout.release(); b.db0.release(); b.out.release();
+    }
+    if (tx->ev_in) (void)hipEventDestroy(tx->ev_in);
+    if (tx->ev_dec) (void)hipEventDestroy(tx->ev_dec);
+    for (int i = 0; i < 2; ++i) if (tx->ev_itp[i]) (void)hipEventDestroy(tx->ev_itp[i]);
     delete tx;
+}
+
+extern "C" int sdrhip_tx_set_pipelined(sdrhip_tx *tx, int on)
+{
+    if (!tx) return fail(SDRHIP_EINVAL, "tx is NULL");
+    sdrhip::CtxLock lock_(tx->ctx);
+    if (!on && tx->late.have) return fail(SDRHIP_EINVAL, "tx_set_pipelined: sdrhip_tx_flush the waiting batch first");
+    if (on) {
+        HIP_TRY(hipSetDevice(tx->ctx->device));
+        if (!tx->ev_in) HIP_TRY(hipEventCreateWithFlags(&tx->ev_in, hipEventDisableTiming));
+        if (!tx->ev_dec) HIP_TRY(hipEventCreateWithFlags(&tx->ev_dec, hipEventDisableTiming));
+        for (int i = 0; i < 2; ++i) if (!tx->ev_itp[i]) HIP_TRY(hipEventCreateWithFlags(&tx->ev_itp[i], hipEventDisableTiming));
+    }
+    tx->pipelined = on ? 1 : 0;
+    return SDRHIP_OK;
+}
+
+namespace {
+// decode S x nframes frames into `pay` ([S][pstride] samples): one batch, or one call per stream when the rows are padded
+int tx_decode(sdrhip_tx *tx, const uint8_t *drx, const uint8_t *indices, size_t nframes, DevBuf &pay, size_t pstride, const DecodeSide *side,
+              uint8_t *block0 = nullptr) // block0 (optional, device): [stream * nframes][508], the frames' meta blocks
+{
+    sdrhip_ctx *c = tx->ctx;
+    const int S = tx->nstreams;
+    const size_t fb = (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE, n_payload = nframes * SDRHIP_SAMPLES_PER_FRAME;
+    int rc;
+    if (pstride == n_payload)
+        return fec_decode_device(c, drx, fb, indices, (size_t)S * nframes, pay.as<uint8_t>(), (size_t)127 * SDRHIP_BLOCK_BYTES, block0, side);
+    for (int s = 0; s < S; ++s)
+        if ((rc = fec_decode_device(c, drx + (size_t)s * nframes * fb, fb, indices ? indices + (size_t)s * nframes * SDRHIP_NB_ORIGINAL : nullptr, nframes,
+                                    pay.as<uint8_t>() + (size_t)s * pstride * 4, (size_t)127 * SDRHIP_BLOCK_BYTES,
+                                    block0 ? block0 + (size_t)s * nframes * SDRHIP_BLOCK_BYTES : nullptr, side)))
+            return rc;
+    return SDRHIP_OK;
+}
+
+// interpolate a decoded batch on the first stream into the caller's buffer (host: through outbuf + a download)
+int tx_interpolate(sdrhip_tx *tx, int log2interp, const DevBuf &pay, size_t n_payload, size_t pstride, int16_t *iq_out, size_t out_stride, int mem)
+{
+    sdrhip_ctx *c = tx->ctx;
+    const int S = tx->nstreams;
+    const size_t n_res = n_payload << log2interp;
+    int16_t *dout = iq_out;
+    size_t dos = out_stride;
+    int rc;
+    if (mem == SDRHIP_MEM_HOST) {
+        dos = (n_res + 3) & ~(size_t)3;
+        if ((rc = tx->outbuf.reserve((size_t)S * dos * 4 + 16))) return rc;
+        dout = tx->outbuf.as<int16_t>();
+    }
+    if ((rc = interpolate_device(tx->itp, log2interp, pay.as<int16_t>(), n_payload, pstride, dout, dos, nullptr))) return rc;
+    if (mem == SDRHIP_MEM_HOST)
+        HIP_TRY(hipMemcpy2DAsync(iq_out, out_stride * 4, dout, dos * 4, n_res * 4, S, hipMemcpyDeviceToHost, c->stream));
+    return SDRHIP_OK;
+}
+
+// delivery half of a pipelined call (and of sdrhip_tx_flush): the waiting batch through the interpolator on the first stream
+int tx_deliver_late(sdrhip_tx *tx, int16_t *iq_out, size_t out_stride, size_t *n_out, int mem)
+{
+    sdrhip_ctx *c = tx->ctx;
+    const int S = tx->nstreams;
+    const size_t n_res = tx->late.n_payload << tx->late.log2interp;
+    if (S == 1) out_stride = n_res;
+    if (!iq_out) return fail(SDRHIP_EINVAL, "tx: NULL output buffer for the waiting batch");
+    if (out_stride < n_res) return fail(SDRHIP_EINVAL, "tx: out_stride smaller than the waiting batch (%zu samples per stream)", n_res);
+    if (mem == SDRHIP_MEM_DEVICE && (!aligned16(iq_out) || (S > 1 && (out_stride & 3)))) return fail(SDRHIP_EALIGN, "tx_process: device output must be 16-byte aligned");
+    const int sel = tx->psel ^ 1; // (psel already points at the buffer the NEXT decode fills)
+    HIP_TRY(hipStreamWaitEvent(c->stream, tx->ev_dec, 0));
+    int rc = tx_interpolate(tx, tx->late.log2interp, tx->payload[sel], tx->late.n_payload, tx->late.pstride, iq_out, out_stride, mem);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(tx->ev_itp[sel], c->stream));
+    tx->itp_pending[sel] = true;
+    tx->late.have = false;
+    if (n_out) *n_out = n_res;
+    return SDRHIP_OK;
+}
+} // namespace
+
+extern "C" int sdrhip_tx_flush(sdrhip_tx *tx, int16_t *iq_out, size_t out_stride, size_t *n_out, int mem)
+{
+    if (!tx) return fail(SDRHIP_EINVAL, "tx is NULL");
+    sdrhip::CtxLock lock_(tx->ctx);
+    if (n_out) *n_out = 0;
+    if (mem != SDRHIP_MEM_HOST && mem != SDRHIP_MEM_DEVICE) return fail(SDRHIP_EINVAL, "mem must be SDRHIP_MEM_HOST or SDRHIP_MEM_DEVICE");
+    if (!tx->late.have) return SDRHIP_OK;
+    HIP_TRY(hipSetDevice(tx->ctx->device));
+    int rc = tx_deliver_late(tx, iq_out, out_stride, n_out, mem);
+    if (rc) return rc;
+    if (mem == SDRHIP_MEM_HOST) HIP_TRY(hipStreamSynchronize(tx->ctx->stream));
+    return SDRHIP_OK;
+}
+
+extern "C" size_t sdrhip_tx_pending_samples(const sdrhip_tx *tx)
+{
+    if (!tx) return 0;
+    sdrhip::CtxLock lock_(tx->ctx);
+    return tx->late.have ? tx->late.n_payload << tx->late.log2interp : 0;
 }
 
 extern "C" int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t *indices, size_t nframes, size_t rx_stride_bytes,
@@ -831,49 +992,188 @@ extern "C" int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t
     sdrhip::CtxLock lock_(tx->ctx);
     const size_t n_payload = nframes * SDRHIP_SAMPLES_PER_FRAME;
     const size_t n_res = n_payload << tx->log2interp;
-    if (n_out) *n_out = n_res;
-    if (nframes == 0) return SDRHIP_OK;
-    if (!rx || !iq_out) return fail(SDRHIP_EINVAL, "tx_process: NULL buffer");
+    if (n_out) *n_out = tx->pipelined ? 0 : n_res;
+    if (mem != SDRHIP_MEM_HOST && mem != SDRHIP_MEM_DEVICE) return fail(SDRHIP_EINVAL, "mem must be SDRHIP_MEM_HOST or SDRHIP_MEM_DEVICE");
+    if (nframes == 0) {
+        // an empty call decodes nothing; in pipelined mode it still delivers the batch that waits
+        if (tx->pipelined && tx->late.have) return sdrhip_tx_flush(tx, iq_out, out_stride, n_out, mem);
+        return SDRHIP_OK;
+    }
+    if (!rx || (!iq_out && !tx->pipelined)) return fail(SDRHIP_EINVAL, "tx_process: NULL buffer");
     sdrhip_ctx *c = tx->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const int S = tx->nstreams;
     const size_t fb = (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE;
-    if (S == 1) { rx_stride_bytes = nframes * fb; out_stride = n_res; }
-    if (rx_stride_bytes < nframes * fb || out_stride < n_res) return fail(SDRHIP_EINVAL, "tx_process: stride too small");
+    if (S == 1) { rx_stride_bytes = nframes * fb; if (!tx->pipelined) out_stride = n_res; }
+    if (rx_stride_bytes < nframes * fb || (!tx->pipelined && out_stride < n_res)) return fail(SDRHIP_EINVAL, "tx_process: stride too small");
+    if (mem == SDRHIP_MEM_DEVICE && S > 1 && rx_stride_bytes != nframes * fb) return fail(SDRHIP_EINVAL, "tx_process: device rx must be contiguous per stream");
+    const size_t pstride = (n_payload + 3) & ~(size_t)3; // samples
     int rc;
+
+    if (tx->pipelined) {
+        // ---- first stream: the batch that waits goes through the interpolator (enqueued FIRST: the long kernel takes the CUs, the
+        // decoder's workgroups fill in as its waves retire); second stream: this call's batch is decoded beside it
+        const bool overlap = c->opt.tx_overlap != 0;
+        hipStream_t s2 = c->stream;
+        if (overlap && (rc = ctx_stream2(c, &s2))) return rc;
+        if (mem == SDRHIP_MEM_DEVICE && overlap) HIP_TRY(hipEventRecord(tx->ev_in, c->stream)); // (whatever produced rx on the caller's stream)
+        if (tx->late.have) {
+            if ((rc = tx_deliver_late(tx, iq_out, out_stride, n_out, mem))) return rc;
+        }
+        const int sel = tx->psel;
+        DevBuf &pay = tx->payload[sel];
+        if (pay.cap < (size_t)S * pstride * 4 + 16) {
+            // (growing the buffer frees it: nothing may still read it)
+            if (tx->itp_pending[sel]) { HIP_TRY(hipEventSynchronize(tx->ev_itp[sel])); tx->itp_pending[sel] = false; }
+            if ((rc = pay.reserve((size_t)S * pstride * 4 + 16))) return rc;
+        }
+        const uint8_t *drx = rx;
+        if (mem == SDRHIP_MEM_HOST) {
+            if (overlap) HIP_TRY(hipStreamSynchronize(s2)); // (the previous decode may still read rxbuf; it ran beside the previous call's interpolator)
+            if ((rc = tx->rxbuf.reserve((size_t)S * nframes * fb))) return rc;
+            HIP_TRY(hipMemcpy2DAsync(tx->rxbuf.p, nframes * fb, rx, rx_stride_bytes, nframes * fb, S, hipMemcpyHostToDevice, s2));
+            drx = tx->rxbuf.as<uint8_t>();
+        } else if (overlap) {
+            HIP_TRY(hipStreamWaitEvent(s2, tx->ev_in, 0));
+        }
+        if (overlap && tx->itp_pending[sel]) { HIP_TRY(hipStreamWaitEvent(s2, tx->ev_itp[sel], 0)); tx->itp_pending[sel] = false; }
+        DecodeSide side;
+        side.stream = s2; side.plan = &tx->plan_own; side.idx = &tx->idx_own; side.pin = &tx->pin_own;
+        if ((rc = tx_decode(tx, drx, indices, nframes, pay, pstride, overlap ? &side : nullptr))) return rc;
+        HIP_TRY(hipEventRecord(tx->ev_dec, s2));
+        tx->late.have = true; tx->late.n_payload = n_payload; tx->late.pstride = pstride; tx->late.log2interp = tx->log2interp;
+        tx->psel ^= 1;
+        if (mem == SDRHIP_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream)); // (the delivered samples; the decode goes on)
+        return SDRHIP_OK;
+    }
+
     const uint8_t *drx = rx;
     if (mem == SDRHIP_MEM_HOST) {
         if ((rc = tx->rxbuf.reserve((size_t)S * nframes * fb))) return rc;
         HIP_TRY(hipMemcpy2DAsync(tx->rxbuf.p, nframes * fb, rx, rx_stride_bytes, nframes * fb, S, hipMemcpyHostToDevice, c->stream));
         drx = tx->rxbuf.as<uint8_t>();
-    } else if (mem == SDRHIP_MEM_DEVICE) {
-        if (!aligned16(iq_out) || (S > 1 && (out_stride & 3))) return fail(SDRHIP_EALIGN, "tx_process: device output must be 16-byte aligned");
-        if (S > 1 && rx_stride_bytes != nframes * fb) return fail(SDRHIP_EINVAL, "tx_process: device rx must be contiguous per stream");
     } else {
-        return fail(SDRHIP_EINVAL, "mem must be SDRHIP_MEM_HOST or SDRHIP_MEM_DEVICE");
+        if (!aligned16(iq_out) || (S > 1 && (out_stride & 3))) return fail(SDRHIP_EALIGN, "tx_process: device output must be 16-byte aligned");
     }
     // decode all S * nframes frames in one batch: payload [S][nframes][127 * 508] = [S][n_payload] samples
-    const size_t pstride = (n_payload + 3) & ~(size_t)3; // samples
-    if ((rc = tx->payload.reserve((size_t)S * pstride * 4 + 16))) return rc;
-    if (pstride == n_payload) {
-        if ((rc = fec_decode_device(c, drx, fb, indices, (size_t)S * nframes, tx->payload.as<uint8_t>(), (size_t)127 * SDRHIP_BLOCK_BYTES, nullptr))) return rc;
-    } else {
-        for (int s = 0; s < S; ++s)
-            if ((rc = fec_decode_device(c, drx + (size_t)s * nframes * fb, fb, indices ? indices + (size_t)s * nframes * SDRHIP_NB_ORIGINAL : nullptr, nframes,
-                                        tx->payload.as<uint8_t>() + (size_t)s * pstride * 4, (size_t)127 * SDRHIP_BLOCK_BYTES, nullptr)))
-                return rc;
+    if ((rc = tx->payload[0].reserve((size_t)S * pstride * 4 + 16))) return rc;
+    if ((rc = tx_decode(tx, drx, indices, nframes, tx->payload[0], pstride, nullptr))) return rc;
+    if ((rc = tx_interpolate(tx, tx->log2interp, tx->payload[0], n_payload, pstride, iq_out, out_stride, mem))) return rc;
+    if (mem == SDRHIP_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDRHIP_OK;
+}
+
+// --------------------------------------------------------------------------- asynchronous host-pointer Tx entry
+// sdrdaemontx's chain is asynchronous as well: a reader thread keeps receiving super blocks while the main loop interpolates
+// (sdrdaemontx.cpp:449-498), and SDRdaemonFECBuffer hands a frame out one frame late (SDRdaemonFECBuffer.cpp:133-139).
+// sdrhip_tx_process on host pointers is upload + three launches + download + a synchronisation per call; submit / collect give
+// the host-pointer path the reference's asynchrony: a batch of received frames goes out as ONE upload + decode + interpolate +
+// download on the context's stream and the call returns; the samples (and the frames' meta blocks) are collected later, in order.
+extern "C" int sdrhip_tx_set_async(sdrhip_tx *tx, int depth)
+{
+    if (!tx) return fail(SDRHIP_EINVAL, "tx is NULL");
+    sdrhip::CtxLock lock_(tx->ctx);
+    if (depth < 1 || depth > 64) return fail(SDRHIP_EINVAL, "tx_set_async: depth 1..64");
+    for (auto &b : tx->abatch)
+        if (b.state != 0) return fail(SDRHIP_EINVAL, "tx_set_async: batches are in flight: collect them first");
+    for (auto &b : tx->abatch) { if (b.done) (void)hipEventDestroy(b.done); b.in.release(); b.din.release(); b.dout.release(); b.db0.release(); b.out.release(); }
+    tx->abatch.assign((size_t)depth, sdrhip_tx::ABatch());
+    tx->a_head = tx->a_tail = 0;
+    return SDRHIP_OK;
+}
+
+extern "C" int sdrhip_tx_submit(sdrhip_tx *tx, const uint8_t *rx, const uint8_t *indices, size_t nframes, size_t rx_stride_bytes)
+{
+    if (!tx) return fail(SDRHIP_EINVAL, "tx is NULL");
+    sdrhip::CtxLock lock_(tx->ctx);
+    if (nframes == 0) return SDRHIP_OK;
+    if (!rx) return fail(SDRHIP_EINVAL, "tx_submit: NULL input");
+    if (tx->pipelined) return fail(SDRHIP_EINVAL, "tx_submit: the handle is in pipelined mode (sdrhip_tx_process delivers one call late there); use one or the other");
+    if (tx->abatch.empty()) tx->abatch.assign(4, sdrhip_tx::ABatch());
+    sdrhip_ctx *c = tx->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const int S = tx->nstreams;
+    const size_t fb = (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE, row = nframes * fb;
+    if (S == 1) rx_stride_bytes = row;
+    if (rx_stride_bytes < row) return fail(SDRHIP_EINVAL, "tx_submit: stride too small");
+    sdrhip_tx::ABatch &b = tx->abatch[tx->a_tail % tx->abatch.size()];
+    if (b.state == 2) return fail(SDRHIP_EBUSY, "tx_submit: every batch of the ring is in flight: sdrhip_tx_collect first");
+    const size_t n_payload = nframes * SDRHIP_SAMPLES_PER_FRAME, n_res = n_payload << tx->log2interp;
+    const size_t pstride = (n_payload + 3) & ~(size_t)3, dos = (n_res + 3) & ~(size_t)3;
+    const size_t b0_bytes = (size_t)S * nframes * SDRHIP_BLOCK_BYTES;
+    int rc;
+    // everything that can fail for want of memory comes first
+    if ((rc = b.din.reserve((size_t)S * row))) return rc;
+    if ((rc = b.dout.reserve((size_t)S * dos * 4 + 16))) return rc;
+    if ((rc = b.db0.reserve(b0_bytes))) return rc;
+    if ((rc = b.out.reserve((size_t)S * dos * 4 + b0_bytes))) return rc;
+    if ((rc = tx->payload[0].reserve((size_t)S * pstride * 4 + 16))) return rc;
+    if (!b.done && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) { b.done = nullptr; return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
+    const uint8_t *src = rx;
+    size_t sstride = rx_stride_bytes;
+    if (!host_is_pinned(rx, (size_t)(S - 1) * rx_stride_bytes + row)) {
+        if ((rc = b.in.reserve((size_t)S * row))) return rc; // (waits for the upload of the batch that used this buffer last)
+        for (int s = 0; s < S; ++s) memcpy(b.in.as<char>() + (size_t)s * row, rx + (size_t)s * rx_stride_bytes, row);
+        src = b.in.as<uint8_t>(); sstride = row;
     }
-    int16_t *dout = iq_out;
-    size_t dos = out_stride;
-    if (mem == SDRHIP_MEM_HOST) {
-        dos = (n_res + 3) & ~(size_t)3;
-        if ((rc = tx->outbuf.reserve((size_t)S * dos * 4 + 16))) return rc;
-        dout = tx->outbuf.as<int16_t>();
+    if (S == 1) HIP_TRY(hipMemcpyAsync(b.din.p, src, row, hipMemcpyHostToDevice, c->stream));
+    else HIP_TRY(hipMemcpy2DAsync(b.din.p, row, src, sstride, row, S, hipMemcpyHostToDevice, c->stream));
+    if (src != rx) b.in.mark(c->stream);
+    if ((rc = tx_decode(tx, b.din.as<uint8_t>(), indices, nframes, tx->payload[0], pstride, nullptr, b.db0.as<uint8_t>()))) return rc;
+    if ((rc = interpolate_device(tx->itp, tx->log2interp, tx->payload[0].as<int16_t>(), n_payload, pstride, b.dout.as<int16_t>(), dos, nullptr))) return rc;
+    // (from here on the interpolator's state has advanced: a failure loses the batch, it is never replayed)
+    hipError_t e = hipMemcpyAsync(b.out.p, b.dout.p, (size_t)S * dos * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(b.out.as<char>() + (size_t)S * dos * 4, b.db0.p, b0_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(b.done, c->stream);
+    if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "tx batch download: %s (the batch's %zu frames per stream are lost)", hipGetErrorString(e), nframes);
+    b.nframes = nframes; b.n_res = n_res; b.dos = dos;
+    b.state = 2;
+    ++tx->a_tail;
+    return SDRHIP_OK;
+}
+
+extern "C" int sdrhip_tx_collect(sdrhip_tx *tx, int16_t *iq_out, size_t out_stride, size_t max_samples, uint8_t *block0_out, size_t *n_out, size_t *n_frames, int wait)
+{
+    if (!tx || !n_out) return fail(SDRHIP_EINVAL, "tx_collect: NULL argument");
+    // (the wait happens outside the context lock: the submitting thread -- the reference's reader thread -- keeps feeding the ring)
+    std::unique_lock<std::recursive_mutex> lock_(tx->ctx->mtx);
+    *n_out = 0;
+    if (n_frames) *n_frames = 0;
+    if (tx->abatch.empty()) return fail(SDRHIP_EBUSY, "tx_collect: nothing was submitted");
+    HIP_TRY(hipSetDevice(tx->ctx->device));
+    sdrhip_tx::ABatch *bp = nullptr;
+    for (;;) {
+        sdrhip_tx::ABatch &h = tx->abatch[tx->a_head % tx->abatch.size()];
+        if (h.state == 0) return fail(SDRHIP_EBUSY, "tx_collect: nothing was submitted");
+        const hipError_t q = hipEventQuery(h.done);
+        if (q == hipSuccess) { bp = &h; break; }
+        if (q != hipErrorNotReady) return fail(SDRHIP_EDEVICE, "hipEventQuery: %s", hipGetErrorString(q));
+        if (!wait) return fail(SDRHIP_EBUSY, "tx_collect: the oldest batch is still in flight");
+        const size_t head = tx->a_head;
+        hipEvent_t ev = h.done;
+        lock_.unlock();
+        const hipError_t w = hipEventSynchronize(ev);
+        lock_.lock();
+        if (w != hipSuccess) return fail(SDRHIP_EDEVICE, "hipEventSynchronize: %s", hipGetErrorString(w));
+        if (tx->a_head == head) { bp = &tx->abatch[head % tx->abatch.size()]; break; }
     }
-    if ((rc = interpolate_device(tx->itp, tx->log2interp, tx->payload.as<int16_t>(), n_payload, pstride, dout, dos, nullptr))) return rc;
-    if (mem == SDRHIP_MEM_HOST) {
-        HIP_TRY(hipMemcpy2DAsync(iq_out, out_stride * 4, dout, dos * 4, n_res * 4, S, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+    sdrhip_tx::ABatch &b = *bp;
+    const int S = tx->nstreams;
+    if (b.n_res > max_samples) { // (the batch stays where it is: call again with room for *n_out samples per stream)
+        *n_out = b.n_res;
+        if (n_frames) *n_frames = b.nframes;
+        return fail(SDRHIP_EINVAL, "tx_collect: the batch holds %zu samples per stream, iq_out has room for %zu", b.n_res, max_samples);
     }
+    if (b.n_res) {
+        if (!iq_out) return fail(SDRHIP_EINVAL, "tx_collect: NULL iq_out");
+        if (S == 1) out_stride = b.n_res;
+        if (out_stride < b.n_res) return fail(SDRHIP_EINVAL, "tx_collect: out_stride too small");
+        for (int s = 0; s < S; ++s) memcpy(iq_out + (size_t)s * out_stride * 2, b.out.as<char>() + (size_t)s * b.dos * 4, b.n_res * 4);
+    }
+    if (block0_out) memcpy(block0_out, b.out.as<char>() + (size_t)S * b.dos * 4, (size_t)S * b.nframes * SDRHIP_BLOCK_BYTES);
+    *n_out = b.n_res;
+    if (n_frames) *n_frames = b.nframes;
+    b.state = 0;
+    ++tx->a_head;
     return SDRHIP_OK;
 }

@@ -647,13 +647,19 @@ class RxPipe:
 
 
 class TxPipe:
-    """SDRdaemonFECBuffer decode -> Upsampler for a bank of streams (sdrhip_tx)."""
+    """SDRdaemonFECBuffer decode -> Upsampler for a bank of streams (sdrhip_tx).  pipelined=True: process() decodes its batch
+    on the context's second stream while the previous batch is interpolated, and returns the PREVIOUS batch's samples
+    (sdrhip_tx_set_pipelined); flush() returns the last batch's at the end.  A device-memory rx batch must stay untouched until
+    the next process() / flush() has returned."""
 
-    def __init__(self, ctx, nstreams=1, log2interp=4):
+    def __init__(self, ctx, nstreams=1, log2interp=4, pipelined=False):
         self.ctx, self.nstreams, self.log2interp = ctx, nstreams, log2interp
         self.h = C.c_void_p()
         self.m_error = ""
+        self.pipelined = bool(pipelined)
         check(ctx.lib.sdrhip_tx_create(ctx.h, nstreams, log2interp, C.byref(self.h)))
+        if pipelined:
+            check(ctx.lib.sdrhip_tx_set_pipelined(self.h, 1))
 
     def configure(self, m):
         """The `interp` key of a control message (Upsampler::configure, Upsampler.cpp:31-50) between two batches;
@@ -685,13 +691,67 @@ class TxPipe:
         if indices is not None:  # optional (see fec_decode_frames)
             indices = np.ascontiguousarray(indices, dtype=np.uint8)
         n_res = (F * SAMPLES_PER_FRAME) << self.log2interp
-        pad = (n_res + 3) & ~3
+        if self.pipelined:  # (the call delivers the batch the PREVIOUS call decoded)
+            n_res = self.ctx.lib.sdrhip_tx_pending_samples(self.h)
+        pad = max((n_res + 3) & ~3, 4)
         out = (torch.empty((S, pad, 2), dtype=torch.int16, device=rx.device) if is_t else np.empty((S, pad, 2), np.int16))
         n_out = C.c_size_t(0)
         check(self.ctx.lib.sdrhip_tx_process(self.h, _ptr(rx), C.c_void_p(indices.ctypes.data if indices is not None else 0), F, F * NB_ORIGINAL * UDPSIZE,
                                              _ptr(out), pad, C.byref(n_out), MEM_DEVICE if is_t else MEM_HOST))
-        out = out[:, :n_res]
+        out = out[:, :n_out.value if self.pipelined else n_res]
         return out[0] if squeeze else out
+
+    # ---- asynchronous host-pointer entry (sdrhip_tx_submit / sdrhip_tx_collect)
+    def set_async(self, depth=4):
+        """ring of `depth` batches in flight"""
+        check(self.ctx.lib.sdrhip_tx_set_async(self.h, depth))
+
+    def submit(self, rx, indices=None):
+        """one batch of received frames from host memory, (S, F, 128, 512) uint8 (or (F, 128, 512)); returns at once.  Raises
+        SdrHipError(code SDRHIP_EBUSY = -6) when every batch of the ring is in flight."""
+        if _is_torch(rx):
+            raise TypeError("submit takes host memory")
+        a = np.asarray(rx)
+        if a.ndim == 3:
+            a = a[None]
+        if a.dtype != np.uint8 or a.ndim != 4 or a.shape[0] != self.nstreams or a.shape[2:] != (NB_ORIGINAL, UDPSIZE):
+            raise ValueError("expected (%d, F, 128, 512) uint8" % self.nstreams)
+        if not (a.strides[3] == 1 and a.strides[2] == UDPSIZE and a.strides[1] == NB_ORIGINAL * UDPSIZE):
+            a = np.ascontiguousarray(a)
+        if indices is not None:
+            indices = np.ascontiguousarray(indices, dtype=np.uint8)
+        self._async_frames = getattr(self, "_async_frames", [])
+        check(self.ctx.lib.sdrhip_tx_submit(self.h, _ptr(a), C.c_void_p(indices.ctypes.data if indices is not None else 0), a.shape[1], a.strides[0]))
+        if a.shape[1]:
+            self._async_frames.append((a.shape[1], self.log2interp))
+
+    def collect(self, wait=True, block0=False):
+        """-> the samples of the oldest batch (S, F * 16129 << log2interp, 2) int16 -- with block0=True a pair (samples, meta blocks
+        (S, F, 508) uint8) -- or None when no batch was collected (nothing submitted, or wait=False and the oldest one is in flight)"""
+        pend = getattr(self, "_async_frames", [])
+        F, L = pend[0] if pend else (0, self.log2interp)
+        cap = max((F * SAMPLES_PER_FRAME) << L, 4)
+        out = np.empty((self.nstreams, cap, 2), np.int16)
+        b0 = np.empty((self.nstreams, max(F, 1), BLOCK_BYTES), np.uint8)
+        n_out, nf = C.c_size_t(0), C.c_size_t(0)
+        rc = self.ctx.lib.sdrhip_tx_collect(self.h, _ptr(out), cap, cap, _ptr(b0) if block0 else C.c_void_p(0), C.byref(n_out), C.byref(nf), 1 if wait else 0)
+        if rc == -6:
+            return None
+        check(rc)
+        if pend:
+            pend.pop(0)
+        return (out[:, :n_out.value], b0[:, :nf.value]) if block0 else out[:, :n_out.value]
+
+    def flush(self, device=None):
+        """pipelined mode: the samples of the batch the last process() call decoded (sdrhip_tx_flush); (S, 0, 2) when nothing
+        waits.  device: a torch device for a device-memory result, None for numpy"""
+        S = self.nstreams
+        n_res = self.ctx.lib.sdrhip_tx_pending_samples(self.h)
+        pad = max((n_res + 3) & ~3, 4)
+        out = torch.empty((S, pad, 2), dtype=torch.int16, device=device) if device is not None else np.empty((S, pad, 2), np.int16)
+        n_out = C.c_size_t(0)
+        check(self.ctx.lib.sdrhip_tx_flush(self.h, _ptr(out), pad, C.byref(n_out), MEM_DEVICE if device is not None else MEM_HOST))
+        return out[:, :n_out.value]
 
     def close(self):
         if self.h:

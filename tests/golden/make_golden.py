@@ -158,6 +158,38 @@ def headline_golden():
         json.dump(out, f, indent=0)
 
 
+def _headline_stream_job(args):
+    from oracle_lib import Oracle
+
+    n, seed = args
+    return seed, _headline_stream(Reference("eo1"), Oracle(), n, seed)
+
+
+def headline64_golden(procs=8):
+    """config 5's bank at the benchmark's step size (round 5: one layout across N): 64 streams x 2^25 samples, the job
+    `bench.py --gpus N` runs for every N > 1 and, as an extra `configs` line, at N = 1.  Same recipe as headline_golden (compiled
+    reference decimate16_cen -> oracle framer + encoder), one process per stream.  -> key "bank64_25" of headline_golden.json
+    (the first 8 streams are bank8's)."""
+    import multiprocessing as mp
+
+    path = os.path.join(HERE, "headline_golden.json")
+    with open(path) as f:
+        out = json.load(f)
+    seeds, log2n = list(range(1000, 1064)), 25
+    res = {}
+    for i, seed in enumerate(out["bank8"]["seeds"]):  # (already made, by the same function)
+        res[seed] = (out["bank8"]["dec_sha256"][i], out["bank8"]["frames_sha256"][i], out["bank8"]["nframes"][i])
+    todo = [(1 << log2n, seed) for seed in seeds if seed not in res]
+    with mp.Pool(procs) as pool:
+        for seed, r in pool.imap_unordered(_headline_stream_job, todo):
+            res[seed] = r
+            print("headline bank64_25", seed, r[0][:12], r[1][:12], r[2], flush=True)
+    out["bank64_25"] = {"seeds": seeds, "log2n": log2n, "dec_sha256": [res[s][0] for s in seeds],
+                        "frames_sha256": [res[s][1] for s in seeds], "nframes": [res[s][2] for s in seeds]}
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+
+
 def tx_headline_golden():
     """Whole-output digests of the BENCHMARKED Tx launch: bench.py's configs[3] -- the first 128 frames of
     every stream of the bank8 Rx run above (reference decimator -> oracle framer + encoder), 24 of 160 blocks lost per frame
@@ -252,6 +284,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "headline":
         headline_golden()
         tx_headline_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "headline64":
+        headline64_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "tx_headline":
         tx_headline_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "long":

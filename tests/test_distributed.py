@@ -133,6 +133,37 @@ def test_bench_gpus_2_as_a_plain_process():
     assert res["verified"]["ok"] is True
 
 
+@pytest.mark.gpu
+def test_bench_n1_names_the_same_64_streams_as_n2():
+    """One layout across N: the N = 1 run carries the job of N = 2 / 4 / 8 -- SURVEY 8e's bank of 64 streams -- as
+    a `configs` line with the same stream ids that `--gpus 2` deals s mod 2 (test_bench_gpus_2_as_a_plain_process), verified like
+    the headline; with SDRHIP_BENCH_SCALE=1 (a scaling sweep) that job IS the N = 1 headline."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SDRHIP_BENCH_STREAMS", "SDRHIP_BENCH_SCALE")}
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0",
+            "--preroll-seconds", "0.05", "--log2-samples", "22"]
+    r = subprocess.run(base, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["scaling"] == "weak" and res["config"]["layout"].startswith("weak") and res["config"]["stream_ids_by_rank"] == [list(range(8))]
+    line = res["configs"][-1]
+    assert line["layout"] == "strong" and line["streams_total"] == 64 and line["stream_ids"] == list(range(64))
+    n2 = [list(range(0, 64, 2)), list(range(1, 64, 2))]  # what --gpus 2 deals (asserted on the real run in the test above)
+    assert sorted(n2[0] + n2[1]) == line["stream_ids"]
+    assert line["verified"]["ok"] is True and "headline_golden.json" in line["verified"]["against"]  # (64 x 2^22: the committed bank64 digests)
+    assert all(c["verified"]["ok"] is True for c in res["configs"]), [c["config"][:40] for c in res["configs"] if not c["verified"]["ok"]]
+    assert res["box"] is None or res["box"]["power_w"] > 0
+    r = subprocess.run(base + ["--no-configs"], capture_output=True, text=True, timeout=900, cwd=root, env=dict(env, SDRHIP_BENCH_SCALE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["scaling"] == "strong" and res["config"]["streams_total"] == 64
+    assert res["config"]["stream_ids_by_rank"] == [list(range(64))] and res["verified"]["ok"] is True
+
+
 def test_bench_gpus_n_without_enough_gpus_refuses_cleanly():
     """nccl with fewer visible GPUs than ranks: a message and exit code 2, not an assertion from inside torch (CPU box: 0 GPUs)"""
     import subprocess

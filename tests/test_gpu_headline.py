@@ -23,6 +23,15 @@ def ctx():
     return sd.Context(0)
 
 
+@pytest.fixture(params=[1, 3], ids=["fused-launch", "two-streams"])
+def plumbing(request, ctx):
+    """where a pipelined pipe runs the waiting encode: inside the next decimator launch (rx_fused_kernel) or on the context's
+    second stream beside it (overlap mode: LDS-DMA ring of depth 3, encoder workgroups co-resident)"""
+    ctx.set_option("rx_fused", request.param)
+    yield request.param
+    ctx.set_option("rx_fused", 1)
+
+
 def _bank(name):
     import torch
 
@@ -74,6 +83,28 @@ def test_headline_bank_8_x_2p25(ctx):
     plan = rx.last_plan()
     assert plan["path"] == "mfma" and plan["wps"] == 124 and plan["span"] == 33792, plan
     _check_frames(view, b)
+
+
+def test_headline_bank_ring_depth_3(ctx):
+    """the LDS-DMA ring of depth 3 (108 KiB per workgroup: what the decimator runs beside the encoder in overlap mode), on its
+    own: the reference digests of the 8 x 2^25 bank"""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    x, b = _bank("bank8")
+    S, n = x.shape[0], x.shape[1]
+    ctx.set_option("mfma_ring", 3)
+    try:
+        d = sd.Decimators(ctx, S, sd.HB_EO1)
+        y = torch.empty((S, n >> 4, 2), dtype=torch.int16, device=x.device)
+        d.decimate(4, sd.FC_CEN, 16, x, out=y)
+        ctx.synchronize()
+        assert d.last_plan()["path"] == "mfma"
+        for s in range(S):
+            assert _sha(y[s]) == b["dec_sha256"][s], ("decimated stream", s)
+    finally:
+        ctx.set_option("mfma_ring", 4)
 
 
 @pytest.mark.parametrize("fused", [0, 1])
@@ -172,7 +203,7 @@ def test_reference_goldens_through_both_kernels(ctx, path):
         ctx.set_option("mfma_span", 0)
 
 
-def test_headline_pipelined_fused_launch(ctx):
+def test_headline_pipelined_fused_launch(ctx, plumbing):
     """bench.py's pipelined step: call N's decimator launch carries the encoder workgroups of call N - 1's frames
     (rx_fused_kernel).  Two steps over the same bank + flush: step 1 delivers nothing, step 2 delivers step 1's frames =
     the reference digests; the flushed frames (second step: streams continue, filter history) equal the unpipelined pipe's."""
@@ -200,7 +231,7 @@ def test_headline_pipelined_fused_launch(ctx):
 
 
 @pytest.mark.parametrize("cfg", [(4, 32, 1), (4, 32, 3), (3, 16, 2), (2, 32, 1), (4, 8, 1), (1, 32, 2), (5, 32, 1)])
-def test_pipelined_equals_unpipelined_ragged(ctx, oracle, cfg):
+def test_pipelined_equals_unpipelined_ragged(ctx, oracle, cfg, plumbing):
     """pipelined mode on ragged host calls (frames straddling calls, calls too short for the matrix cores, the generic encoder
     at nb_fec = 8, the VALU path at decimate2, decimate32 = no fused launch): same frames, one call later, flush at the end"""
     import sdrdaemon_amd as sd
@@ -301,6 +332,109 @@ def test_headline_tx_bank_8_x_128_frames(ctx, max_rows, dec_path):
         ctx.set_option("dec_path", "syndrome")
 
 
+@pytest.mark.parametrize("overlap", [1, 0], ids=["two-streams", "one-stream"])
+def test_headline_tx_bank_pipelined(ctx, overlap):
+    """bench.py's pipelined configs[3] step (sdrhip_tx_set_pipelined): call N decodes its batch on the second stream while the
+    first one interpolates batch N - 1 and delivers it.  Three calls on the same received frames + flush: call 1 delivers nothing,
+    call 2 delivers batch 1 = the reference digests (tx_bank8), the later deliveries equal the unpipelined pipe's second and third
+    outputs (the interpolator histories continue)."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    T = H["tx_bank8"]
+    rxf, _ = _tx_input(ctx)
+    S, F = rxf.shape[0], rxf.shape[1]
+    ctx.set_option("dec_max_rows", 32)
+    ctx.set_option("tx_overlap", overlap)
+    try:
+        ref = sd.TxPipe(ctx, S, T["log2interp"])
+        ref.process(rxf)
+        second = ref.process(rxf).clone()
+        third_sha = [_sha(v) for v in ref.process(rxf)]
+        del ref
+        tx = sd.TxPipe(ctx, S, T["log2interp"], pipelined=True)
+        v0 = tx.process(rxf)
+        assert v0.shape == (S, 0, 2)
+        v1 = tx.process(rxf)
+        ctx.synchronize()
+        assert v1.shape == (S, (F * 16129) << T["log2interp"], 2)
+        for s in range(S):
+            assert _sha(v1[s]) == T["iq_sha256"][s], ("pipelined tx output of stream", s)
+        del v1
+        v2 = tx.process(rxf)
+        ctx.synchronize()
+        assert torch.equal(v2, second)
+        del v2, second
+        v3 = tx.flush(device=rxf.device)
+        ctx.synchronize()
+        assert [_sha(v) for v in v3] == third_sha
+        assert tx.flush(device=rxf.device).shape == (S, 0, 2)
+    finally:
+        ctx.set_option("dec_max_rows", 128)
+        ctx.set_option("tx_overlap", 1)
+
+
+@pytest.mark.parametrize("overlap,device", [(1, False), (1, True), (0, False)], ids=["two-streams-host", "two-streams-device", "one-stream-host"])
+def test_tx_pipelined_many_ragged_calls(ctx, oracle, overlap, device):
+    """20 pipelined Tx calls of 1..9 frames on two streams, a different random loss pattern per frame, the interpolation factor
+    changed by control messages on the way (a waiting batch keeps the factor it was handed in with), an empty call in the middle
+    (delivers like any other): every delivery equals the unpipelined pipe's output of the previous call, and the whole sample
+    stream equals the oracle chain (decode -> interpolators with carried histories)."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    S, R = 2, 32
+    rs = np.random.RandomState(23)
+    counts = [int(v) for v in rs.choice([1, 2, 3, 5, 9], 20)]
+    counts[6] = 0
+    factors = [4] * 5 + [2] * 5 + [6] * 3 + [3] * 7
+    Ftot = sum(counts)
+    ys = [signals.noise(Ftot * 16129, 300 + s) for s in range(S)]
+    rxb = np.zeros((S, Ftot, 128, 512), np.uint8)
+    for s in range(S):
+        frames = oracle.framer(nb_fec_blocks=R).write(ys[s])
+        for f in range(Ftot):
+            allb = np.concatenate([frames[f], oracle.frame_encode(frames[f], R)])
+            lost = set(rs.choice(160, 24, replace=False).tolist())
+            rxb[s, f] = allb[[i for i in range(160) if i not in lost][:128]]
+    ctx.set_option("tx_overlap", overlap)
+    try:
+        a = sd.TxPipe(ctx, S, 4)
+        p = sd.TxPipe(ctx, S, 4, pipelined=True)
+        pos, prev, got_all = 0, None, []
+        for i, c in enumerate(counts):
+            assert a.configure({"interp": str(factors[i])}) and p.configure({"interp": str(factors[i])})
+            batch = rxb[:, pos:pos + c]
+            pos += c
+            e = a.process(batch) if c else np.zeros((S, 0, 2), np.int16)
+            g = p.process(torch.from_numpy(np.ascontiguousarray(batch)).cuda() if device else batch)
+            g = g.cpu().numpy() if device else g
+            if prev is None:
+                assert g.shape == (S, 0, 2)
+            else:
+                assert g.shape == prev.shape and np.array_equal(g, prev), ("call", i)
+            got_all.append(g)
+            prev = e
+        last = p.flush(device=torch.device("cuda", 0)).cpu().numpy() if device else p.flush()
+        assert np.array_equal(last, prev)
+        got_all.append(last)
+        got = np.concatenate(got_all, axis=1)
+        for s in range(S):
+            ou, exp, q = oracle.interpolators(), [], 0
+            for i, c in enumerate(counts):
+                exp.append(ou.interpolate(factors[i], ys[s][q * 16129:(q + c) * 16129]))
+                q += c
+            assert np.array_equal(got[s], np.concatenate(exp)), ("stream", s)
+        p.process(rxb[:, :1])
+        assert ctx.lib.sdrhip_tx_set_pipelined(p.h, 0) != 0  # refused: a batch waits for delivery
+        p.flush()
+        assert ctx.lib.sdrhip_tx_set_pipelined(p.h, 0) == 0
+    finally:
+        ctx.set_option("tx_overlap", 1)
+
+
 @pytest.mark.parametrize("dec_path", ["syndrome", "dense"])
 def test_dec_max_rows_is_checked_on_the_device(ctx, oracle, dec_path):
     """dec_max_rows is a promise; a frame that breaks it (33 recovery blocks under dec_max_rows = 32) is left as received --
@@ -338,7 +472,7 @@ def test_dec_max_rows_is_checked_on_the_device(ctx, oracle, dec_path):
         ctx.set_option("dec_path", "syndrome")
 
 
-def test_pipelined_many_calls_wrap_the_frame_window(ctx, oracle):
+def test_pipelined_many_calls_wrap_the_frame_window(ctx, oracle, plumbing):
     """24 pipelined calls of varying size -- enough to exceed the frame area (cap_frames = 4 x (frames of the
     biggest call so far + 1)) several times, to wrap it while frames wait for delivery (wrap_hits_late -> a new area, the old
     one handed over as old_work) and to alternate the two stream-order buffers well beyond 4 calls; an empty call in the middle

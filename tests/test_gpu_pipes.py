@@ -355,6 +355,85 @@ def test_tx_pipe_live_interp_change(ctx, oracle):
         assert np.array_equal(got, ou.interpolate(log2, x[f * 16129:(f + 1) * 16129])), (f, log2)
 
 
+@pytest.mark.parametrize("S,log2,pinned", [(1, 0, False), (1, 4, False), (2, 3, True), (2, 6, False)])
+def test_tx_submit_collect_equals_the_synchronous_pipe(ctx, oracle, S, log2, pinned):
+    """sdrhip_tx_submit / sdrhip_tx_collect (asynchronous host-pointer Tx entry): 9 batches of 1..8 received frames
+    (a different random loss pattern per frame), a ring of 3 batches, staged or in place (sdrhip_host_alloc memory); the collected
+    samples, batch by batch, are those of the synchronous pipe fed with the same batches -- and the oracle chain's; the meta blocks
+    come back beside them."""
+    import sdrdaemon_amd as sd
+
+    R = 32
+    rs = np.random.RandomState(5)
+    counts = [int(v) for v in rs.choice([1, 2, 3, 8], 9)]
+    Ftot = sum(counts)
+    ys = [signals.noise(Ftot * 16129, 400 + s) for s in range(S)]
+    rxb = np.zeros((S, Ftot, 128, 512), np.uint8)
+    meta0 = np.zeros((S, Ftot, 508), np.uint8)
+    for s in range(S):
+        frames = oracle.framer(nb_fec_blocks=R).write(ys[s])
+        for f in range(Ftot):
+            allb = np.concatenate([frames[f], oracle.frame_encode(frames[f], R)])
+            lost = set(rs.choice(160, 24, replace=False).tolist())
+            rxb[s, f] = allb[[i for i in range(160) if i not in lost][:128]]
+            meta0[s, f] = frames[f][0, 4:]
+    src = rxb
+    if pinned:
+        src = ctx.host_alloc(rxb.shape, np.uint8)
+        src[:] = rxb
+    a = sd.TxPipe(ctx, S, log2)
+    p = sd.TxPipe(ctx, S, log2)
+    p.set_async(depth=3)
+    exp, got, inflight, pos = [], [], 0, 0
+    for c in counts:
+        p.submit(src[:, pos:pos + c])
+        exp.append(a.process(rxb[:, pos:pos + c]))
+        pos += c
+        inflight += 1
+        if inflight == 3:  # the ring is full
+            with pytest.raises(sd.SdrHipError) as e:
+                p.submit(src[:, :1])
+            assert e.value.code == -6
+            got.append(p.collect(wait=True, block0=True))
+            inflight -= 1
+    while inflight:
+        got.append(p.collect(wait=True, block0=True))
+        inflight -= 1
+    assert p.collect(wait=True) is None and p.collect(wait=False) is None
+    assert len(got) == len(exp)
+    pos = 0
+    for (g, b0), e, c in zip(got, exp, counts):
+        assert g.shape == e.shape and np.array_equal(g, e)
+        assert b0.shape == (S, c, 508) and np.array_equal(b0, meta0[:, pos:pos + c])
+        pos += c
+    whole = np.concatenate([g for g, _ in got], axis=1)
+    for s in range(S):
+        assert np.array_equal(whole[s], oracle.interpolators().interpolate(log2, ys[s])), s
+    if pinned:
+        ctx.host_free(src)
+
+
+def test_tx_collect_refuses_a_buffer_that_is_too_small_and_a_pipelined_handle(ctx, oracle):
+    import ctypes as C
+
+    import sdrdaemon_amd as sd
+
+    y = signals.noise(2 * 16129, 8)
+    frames = oracle.framer(nb_fec_blocks=8).write(y)
+    rxb = np.ascontiguousarray(frames[:, :128])
+    tx = sd.TxPipe(ctx, 1, 2)
+    tx.submit(rxb)
+    tiny = np.empty((100, 2), np.int16)
+    n_out, nf = C.c_size_t(0), C.c_size_t(0)
+    rc = ctx.lib.sdrhip_tx_collect(tx.h, C.c_void_p(tiny.ctypes.data), 0, 100, C.c_void_p(0), C.byref(n_out), C.byref(nf), 1)
+    assert rc == -1 and n_out.value == 2 * 16129 * 4 and nf.value == 2
+    got = tx.collect(wait=True)  # (the batch stayed where it was)
+    assert np.array_equal(got[0], oracle.interpolators().interpolate(2, y))
+    pp = sd.TxPipe(ctx, 1, 2, pipelined=True)
+    with pytest.raises(sd.SdrHipError):
+        pp.submit(rxb)
+
+
 def test_rx_meta_block_is_the_reference_s_literal_record_when_the_clock_does_not_advance(ctx, oracle):
     """the product stamps the frames a call opens from the sample clock (tv + floor(p * 10^6 / rate)); the reference
     stamps them with gettimeofday as they open (UDPSinkFEC.cpp:90-109).  With sample_rate = 0 the clock does not advance and the

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The drop-in mode as sdrdaemonrx sees it: one TestSource-sized block (65 536 samples) per synchronous call through host
-pointers (SDRHIP_MEM_HOST): microseconds per call, against the same call on device-resident data."""
+"""The drop-in mode as sdrdaemonrx / sdrdaemontx see it: one TestSource-sized block (65 536 samples) per synchronous call through
+host pointers (SDRHIP_MEM_HOST): microseconds per call, against the same call on device-resident data; the asynchronous entries
+(sdrhip_rx_submit / collect, sdrhip_tx_submit / collect).  usage: python tools/bench_host_block.py [rx|tx|all]"""
 import os
 import sys
 import time
@@ -13,6 +14,74 @@ import torch  # noqa: E402
 import sdrdaemon_amd as sd  # noqa: E402
 
 ctx = sd.Context(0)
+WHAT = sys.argv[1] if len(sys.argv) > 1 else "all"
+
+
+def tx_section():
+    """Tx side: received frames from host memory (a distinct 24-of-160 loss pattern per frame), decode + interpolate16_cen:
+    the synchronous per-frame call (what UDPSourceFEC::read + Upsampler::process amount to), synchronous batches of 8, and the
+    asynchronous entry with batches of 8 / 32 frames, 3 batches in flight"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import signals
+    import headline_inputs as hi
+
+    x = torch.stack([signals.hash_noise_torch(1 << 25, 1000, "cuda")])
+    meta = {"tv_sec": 1, "tv_usec": 0, "center_frequency_khz": 435000, "sample_rate": 625000, "nb_fec": 32}
+    rxf, _ = hi.tx_received_frames(ctx, x, meta)
+    del x
+    rxh = rxf[0].cpu().numpy()  # (128 frames, 128, 512)
+    F = rxh.shape[0]
+    ctx.set_option("dec_max_rows", 32)
+    for L in (4, 0):
+        tx = sd.TxPipe(ctx, 1, L)
+        for f in range(8):
+            tx.process(rxh[f:f + 1])
+        t0 = time.perf_counter()
+        for f in range(F):
+            tx.process(rxh[f:f + 1])
+        t1 = (time.perf_counter() - t0) / F * 1e6
+        t0 = time.perf_counter()
+        for f in range(0, F, 8):
+            tx.process(rxh[f:f + 8])
+        t8 = (time.perf_counter() - t0) / F * 1e6
+        print("tx pipe (interp x%d), host pointers, synchronous: %7.1f us per frame one frame per call, %7.1f us per frame in calls of 8" % (1 << L, t1, t8), flush=True)
+        for pinned in (False, True):
+            src = rxh
+            if pinned:
+                src = ctx.host_alloc(rxh.shape, np.uint8)
+                src[:] = rxh
+            for bf in (8, 32):
+                p = sd.TxPipe(ctx, 1, L)
+                p.set_async(depth=4)
+
+                def run(rounds):
+                    inflight = 0
+                    for r in range(rounds):
+                        for f in range(0, F, bf):
+                            p.submit(src[f:f + bf])
+                            inflight += 1
+                            if inflight == 3:
+                                p.collect(wait=True)
+                                inflight -= 1
+                    while inflight:
+                        p.collect(wait=True)
+                        inflight -= 1
+                run(1)
+                R = 4
+                t0 = time.perf_counter()
+                run(R)
+                ta = (time.perf_counter() - t0) / (R * F) * 1e6
+                print("tx submit / collect (interp x%d), %2d frames per batch, %s: %7.1f us per frame = %5.1f x the synchronous per-frame call, %7.1f M output samples/s" %
+                      (1 << L, bf, "in place (pinned source)" if pinned else "staged (pageable source) ", ta, t1 / ta, (16129 << L) / ta), flush=True)
+            if pinned:
+                ctx.host_free(src)
+    ctx.set_option("dec_max_rows", 128)
+
+
+if WHAT in ("tx", "all"):
+    tx_section()
+if WHAT == "tx":
+    sys.exit(0)
 for n in (65536, 262144, 1 << 20):
     x = np.random.default_rng(1).integers(-32768, 32768, (n, 2), dtype=np.int16)
     xd = torch.from_numpy(x).cuda()

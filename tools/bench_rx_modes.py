@@ -43,8 +43,12 @@ def run(name, pipelined, fused, path="auto"):
 
 
 res = {}
+ONLY_MODES = os.environ.get("MODES")  # e.g. MODES=immediate,overlap
 for r in range(ROUNDS):
-    for name, args in (("immediate (3 launches)", (False, 1)), ("pipelined, fused launch", (True, 1)), ("pipelined, separate launches", (True, 0)), ("pipelined, fused kernel without encoder units + encoder", (True, 2))):
+    for name, args in (("immediate (3 launches)", (False, 1)), ("pipelined, fused launch", (True, 1)), ("pipelined, separate launches", (True, 0)), ("pipelined, fused kernel without encoder units + encoder", (True, 2)),
+                       ("pipelined, two streams (overlap)", (True, 3))):
+        if ONLY_MODES and not any(k in name for k in ONLY_MODES.split(",")):
+            continue
         res.setdefault(name, []).append(run(name, *args))
 for k, v in res.items():
     print("%-32s %s ms/step  -> %.0f Gsamples/s" % (k, " ".join("%.4f" % t for t in v), S * n / min(v) / 1e6))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised parity hunt on the GPU box (not part of the test suite): random configurations and ragged
-call sequences through the C ABI against the oracle.  usage: python tools/fuzz_gpu.py [seconds] [seed]"""
+"""Randomised parity hunt on the GPU box: random configurations and ragged call sequences through the C ABI against the oracle.
+usage: python tools/fuzz_gpu.py [seconds] [seed] [max iterations, 0 = none]
+(tests/test_gpu_fuzz_slice.py runs a fixed-seed, iteration-capped slice of it inside `pytest -m gpu`)"""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ from oracle_lib import Oracle  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_it = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 orc = Oracle()
 ctx = sd.Context(0)
 t0 = time.time()
@@ -41,7 +43,7 @@ def sizes(rs, scale, k):
 
 
 it = 0
-while time.time() - t0 < budget:
+while time.time() - t0 < budget and (max_it == 0 or it < max_it):
     it += 1
     rs = np.random.RandomState(seed0 * 100003 + it)
     what = rs.choice(["decim", "interp", "rx", "tx", "fec"], p=[0.3, 0.2, 0.2, 0.1, 0.2])
@@ -49,7 +51,9 @@ while time.time() - t0 < budget:
     # inputs run many waves + the VALU head / tail pieces), or the library's own choice
     ctx.set_option("decim_path", str(rs.choice(["auto", "valu", "mfma", "mfma"])))
     ctx.set_option("mfma_span", 1024 * int(rs.choice([1, 1, 2, 3, 5, 16])))
-    ctx.set_option("rx_fused", int(rs.randint(0, 2)))
+    ctx.set_option("rx_fused", int(rs.choice([0, 1, 3])))  # pipelined Rx: the waiting encode in its own launch / inside the decimator's / on the second stream
+    ctx.set_option("mfma_ring", int(rs.choice([3, 4])))      # LDS-DMA ring depth of the decimate16 matrix-core kernel
+    ctx.set_option("tx_overlap", int(rs.randint(0, 2)))      # pipelined Tx: decode on the second stream / on the first
     ctx.set_option("dec_path", str(rs.choice(["syndrome", "syndrome", "dense"])))
     ctx.set_option("interp_path", str(rs.choice(["wave", "wave", "valu"])))     # K5w (default) / K5
     ctx.set_option("interp_span", int(rs.choice([0, 0, 128, 256, 640, 2048])))  # segment length in inputs (0 = the planner's)
@@ -228,15 +232,23 @@ while time.time() - t0 < budget:
                         hole[b - 1] = allb[b, 4:]
                 x[f * 16129:(f + 1) * 16129] = hole.reshape(-1).view(np.int16).reshape(-1, 2)
             rxb[f] = allb[keep]
-        tx = sd.TxPipe(ctx, 1, L)
+        tx_pipelined = bool(rs.rand() < 0.4)  # samples one call late (decode beside the previous batch's interpolator) + flush
+        tx = sd.TxPipe(ctx, 1, L, pipelined=tx_pipelined)
+        cut = int(rs.randint(1, F)) if (tx_pipelined and F > 1) else F  # pipelined: two batches, the second one delivers the first
         if rs.rand() < 0.4:  # frames resident on the device: the planning kernel reads the block indices from the headers
             import torch
 
-            yt = tx.process(torch.from_numpy(rxb).cuda())
+            rxt = torch.from_numpy(rxb).cuda()
+            parts = [tx.process(rxt[:cut])] + ([tx.process(rxt[cut:])] if cut < F else [])
+            if tx_pipelined:
+                parts.append(tx.flush(device=rxt.device)[0])
             ctx.synchronize()
-            y = yt.cpu().numpy().reshape(-1, 2)
+            y = np.concatenate([p_.cpu().numpy().reshape(-1, 2) for p_ in parts])
         else:
-            y = np.asarray(tx.process(rxb)).reshape(-1, 2)
+            parts = [tx.process(rxb[:cut])] + ([tx.process(rxb[cut:])] if cut < F else [])
+            if tx_pipelined:
+                parts.append(tx.flush()[0])
+            y = np.concatenate([np.asarray(p_).reshape(-1, 2) for p_ in parts])
         assert np.array_equal(y, orc.interpolators().interpolate(L, x)), ("tx", it, F, R, L, max_rows)
         assert ctx.counter("dec_rows_exceeded") - exceeded0 == n_exceed, ("tx dec_max_rows counter", it, max_rows, n_exceed)
         ctx.set_option("dec_max_rows", 128)
