@@ -298,10 +298,7 @@ constexpr int MF_GROUP_BYTES = 9216;             // 8 blocks of 1 KiB + their sk
 constexpr int mf_wave_ring(int ng) { return ng * MF_GROUP_BYTES; } // bytes of LDS per wave
 // decimate16 only: measured with 3 interleaved rounds (tools/experiments_r03/exp24.sh), register ring against LDS-DMA ring: decimate16 0.2445 / 0.2363 ms,
 // decimate32 0.2512 / 0.2537, decimate64 0.2693 / 0.2947 (their warm-up and the ring's run-ahead past the span grow with the ratio)
-#ifndef MF_DMA_MAX_NS
-#define MF_DMA_MAX_NS 4 // (experiments: 5 / 6 put decimate32 / 64 on the LDS-DMA ring as well -- their unrolled period is 32 steps too)
-#endif
-__host__ __device__ constexpr bool mf_dma_applies(int ns) { return ns >= 4 && ns <= MF_DMA_MAX_NS; } // (period of 32 steps; one workgroup per CU)
+__host__ __device__ constexpr bool mf_dma_applies(int ns) { return ns == 4; } // (period of 32 steps; one workgroup per CU)
 __host__ __device__ constexpr int mf_block_units(int p) { return 72 * p + 2 * (p >> 2); }
 
 template <int D> __device__ __forceinline__ void mf_dma_issue(unsigned slot, unsigned voff, unsigned long long span_base)

@@ -80,6 +80,40 @@ void cm256_karatsuba_leaf_tables(uint8_t *out)
     }
 }
 
+// CM256's 128-original encode as an additive FFT (Lin, Chung, Han: "Novel polynomial basis and its application to Reed-Solomon
+// erasure codes", 2014).  With x_0 = 128, x_r = 128 ^ r, y_j = j the recovery block is P ^ r * S(x_r), S(x) = sum_j d_j / (x ^ j)
+// (gf_encode128_body.h).  V_k = {0 .. 2^k - 1} is a GF(2)-subspace; s_k = its subspace polynomial (s_0 = x, s_{k+1}(x) = s_k(x)
+// (s_k(x) ^ s_k(2^k)); linearised, so constant on cosets of V_k), s^_k = s_k / s_k(2^k).  S = N / s_7 with N the polynomial of
+// degree < 128 that takes the values c d_j on V7 (c = s_7'(0) = the product of the nonzero elements of V7), and s_7 = q on the
+// whole coset 128 + V7.  In the basis X_i = prod_{bit k of i} s^_k a transform of size 2^m on a coset is m stages of butterflies
+// (a ^= const * b, b ^= a) whose constant is s^_k of the block's coset representative.
+void cm256_fft_tables(uint8_t *out)
+{
+    const GF256 &f = gf();
+    std::vector<uint8_t> all(256 * 32);
+    gf_build_tables(all.data());
+    uint8_t s[8][256], shat[8][256];
+    for (int x = 0; x < 256; ++x) s[0][x] = (uint8_t)x;
+    for (int k = 0; k < 7; ++k)
+        for (int x = 0; x < 256; ++x) s[k + 1][x] = f.mul[s[k][x]][s[k][x] ^ s[k][1 << k]];
+    for (int k = 0; k < 8; ++k)
+        for (int x = 0; x < 256; ++x) shat[k][x] = f.mul[s[k][x]][f.inv[s[k][1 << k]]];
+    uint8_t cst[CM256_FFT_TABLES];
+    memset(cst, 0, sizeof(cst));
+    for (int h = 0; h < 2; ++h)
+        for (int k = 0; k < 6; ++k)
+            for (int j = 0; j < (32 >> k); ++j) cst[63 * h + (64 - (64 >> k)) + j] = shat[k][(64 * h) ^ (j << (k + 1))];
+    cst[126] = shat[5][128];
+    cst[127] = shat[6][128];
+    for (int k = 0; k < 5; ++k)
+        for (int j = 0; j < (16 >> k); ++j) cst[128 + (32 - (32 >> k)) + j] = shat[k][128 ^ (j << (k + 1))];
+    uint8_t c = 1;
+    for (int v = 1; v < 128; ++v) c = f.mul[c][v];
+    const uint8_t q = s[7][128];
+    for (int r = 0; r < 32; ++r) cst[160 + r] = f.mul[f.mul[r][c]][f.inv[q]];
+    for (int i = 0; i < CM256_FFT_TABLES; ++i) memcpy(out + (size_t)i * 32, &all[(size_t)cst[i] * 32], 32);
+}
+
 int cm256_decode_plan(int k, int recovery_count_param, const uint8_t *indices, int *n_rec_out, uint8_t *rec_pos,
                       uint8_t *erased, uint8_t *coef)
 {

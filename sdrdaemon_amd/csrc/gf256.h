@@ -39,6 +39,16 @@ void cm256_encode_matrix(int k, int rows, uint8_t *m /* rows * k */);
 // each as its 32-byte multiplier table (layout of gf_build_tables).
 void cm256_karatsuba_leaf_tables(uint8_t *out /* 8 * 81 * 32 */);
 
+// Constants of the additive-FFT form of the same encoder (gf_encode128_fft.h), each as its 32-byte multiplier table (layout of
+// gf_build_tables), CM256_FFT_TABLES entries:
+//   [63 h + (64 - (64 >> k)) + j]  normalised subspace polynomial s^_k(64 h ^ (j << (k + 1))): butterfly constant of block j of stage
+//                                  k = 0..5 of the size-64 inverse transform on the coset 64 h + V6 (h = 0, 1)
+//   [126], [127]                   s^_5(128), s^_6(128): the fold of the 128 novel-basis coefficients onto the coset 128 + V5
+//   [128 + (32 - (32 >> k)) + j]   s^_k(128 ^ (j << (k + 1))): stage k = 0..4 of the size-32 transform on 128 + V5
+//   [160 + r]                      r * c / q (c = product of the nonzero elements of V7, q = s_7(128)): the scale of recovery row r < 32
+constexpr int CM256_FFT_TABLES = 192;
+void cm256_fft_tables(uint8_t *out /* CM256_FFT_TABLES * 32 */);
+
 // Decode plan for one frame, restating CM256Decoder::Initialize + Decode/DecodeM1:
 // `indices` are the Index fields of the k descriptors in array order.  On success
 //   n_rec         number of recovery descriptors (= erasures repaired)

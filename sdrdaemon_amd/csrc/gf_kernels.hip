@@ -18,6 +18,9 @@
 // registers; a workgroup = 4 waves = 4 x RB rows of the same frames.
 #include "sdrhip_internal.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace sdrhip {
 namespace {
 
@@ -150,6 +153,14 @@ __global__ __launch_bounds__(GF_NT, 4) void gf_encode128_kernel(Enc128Args a) //
     gf_encode128_wg(a, (int)blockIdx.x, ldsraw);
 }
 
+// the additive-FFT encoder (rows <= 32): a workgroup per frame
+#include "gf_encode128_fft.h"
+__global__ __launch_bounds__(GF_NT, 4) void gf_encode128_fft_kernel(Enc128Args a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ldsraw[ENC128_FFT_KERNEL_LDS];
+    gf_encode128_fft_unit(a, (int)blockIdx.x, ldsraw);
+}
+
 // The Rx pipe's last launch: the encoder's workgroups and, behind them, K2's (the frames left open at either end of the call,
 // meta blocks, headers).  One launch instead of two: K2 used to run first because the encoder reads what K2 writes (block 0 of
 // the frames the call starts, the tail of the frame the call completes); now the encoder derives / fetches both itself
@@ -161,6 +172,18 @@ __global__ __launch_bounds__(GF_NT, 4) void gf_encode128_pack_kernel(Enc128Args 
     const unsigned nenc = 2u * (unsigned)a.nlist;
     if (blockIdx.x < nenc) {
         gf_encode128_wg(a, (int)blockIdx.x, ldsraw);
+    } else {
+        const unsigned u = blockIdx.x - nenc;
+        frame_pack_wg(f, (int)(u / pack_bx), u % pack_bx, pack_bx);
+    }
+}
+// ... with the additive-FFT encoder: nlist encoder workgroups in front of K2's
+__global__ __launch_bounds__(GF_NT, 4) void gf_encode128_fft_pack_kernel(Enc128Args a, FrameArgs f, unsigned pack_bx)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ldsraw[ENC128_FFT_KERNEL_LDS];
+    const unsigned nenc = (unsigned)a.nlist;
+    if (blockIdx.x < nenc) {
+        gf_encode128_fft_unit(a, (int)blockIdx.x, ldsraw);
     } else {
         const unsigned u = blockIdx.x - nenc;
         frame_pack_wg(f, (int)(u / pack_bx), u % pack_bx, pack_bx);
@@ -709,7 +732,8 @@ hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream)
 hipError_t launch_gf_encode128(const Enc128Args &a, hipStream_t stream)
 {
     if (a.nlist <= 0 || a.rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gf_encode128_kernel, dim3(2 * a.nlist), dim3(GF_NT), 0, stream, a);
+    if (a.use_fft && a.fft_tables && a.rows <= FFT_MAX_ROWS) hipLaunchKernelGGL(gf_encode128_fft_kernel, dim3(a.nlist), dim3(GF_NT), 0, stream, a);
+    else hipLaunchKernelGGL(gf_encode128_kernel, dim3(2 * a.nlist), dim3(GF_NT), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -718,8 +742,11 @@ hipError_t launch_gf_encode128_pack(const Enc128Args &a, const FrameArgs &f, int
     size_t blocks = (f.n - (f.skip_to - f.skip_from) + 255) / 256;
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    const unsigned nenc = a.rows > 0 ? 2u * (unsigned)(a.nlist > 0 ? a.nlist : 0) : 0u;
-    hipLaunchKernelGGL(gf_encode128_pack_kernel, dim3(nenc + (unsigned)blocks * (unsigned)nstreams), dim3(GF_NT), 0, stream, a, f, (unsigned)blocks);
+    const unsigned units = a.rows > 0 ? 2u * (unsigned)(a.nlist > 0 ? a.nlist : 0) : 0u;
+    if (a.use_fft && a.fft_tables && a.rows > 0 && a.rows <= FFT_MAX_ROWS)
+        hipLaunchKernelGGL(gf_encode128_fft_pack_kernel, dim3(units / 2u + (unsigned)blocks * (unsigned)nstreams), dim3(GF_NT), 0, stream, a, f, (unsigned)blocks);
+    else
+        hipLaunchKernelGGL(gf_encode128_pack_kernel, dim3(units + (unsigned)blocks * (unsigned)nstreams), dim3(GF_NT), 0, stream, a, f, (unsigned)blocks);
     return hipGetLastError();
 }
 

@@ -120,7 +120,7 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
         // sdrhip_ctx_set_option()
         static const char *const keys[][2] = {{"SDRHIP_DECIM_PATH", "decim_path"}, {"SDRHIP_MFMA_SPAN", "mfma_span"}, {"SDRHIP_MFMA_MIN", "mfma_min"},
                                               {"SDRHIP_INTERP_PATH", "interp_path"}, {"SDRHIP_INTERP_SPAN", "interp_span"}, {"SDRHIP_RX_FUSED", "rx_fused"},
-                                              {"SDRHIP_DEC_PATH", "dec_path"}, {"SDRHIP_MFMA_RING", "mfma_ring"}, {"SDRHIP_TX_OVERLAP", "tx_overlap"}};
+                                              {"SDRHIP_DEC_PATH", "dec_path"}, {"SDRHIP_ENC_PATH", "enc_path"}, {"SDRHIP_MFMA_RING", "mfma_ring"}, {"SDRHIP_TX_OVERLAP", "tx_overlap"}};
         for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); ++i)
             if (const char *v = getenv(keys[i][0])) (void)sdrhip_ctx_set_option(c, keys[i][1], v);
     }
@@ -136,6 +136,12 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
     cm256_karatsuba_leaf_tables(kl.data());
     if (hipMalloc(reinterpret_cast<void **>(&c->enc_leaves), kl.size()) != hipSuccess ||
         hipMemcpy(c->enc_leaves, kl.data(), kl.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "upload encoder constants"); }
+    {
+        std::vector<uint8_t> ft((size_t)CM256_FFT_TABLES * 32);
+        cm256_fft_tables(ft.data());
+        if (hipMalloc(reinterpret_cast<void **>(&c->enc_fft), ft.size()) != hipSuccess ||
+            hipMemcpy(c->enc_fft, ft.data(), ft.size(), hipMemcpyHostToDevice) != hipSuccess) { ctx_free(c); return fail(SDRHIP_ENOMEM, "upload encoder FFT constants"); }
+    }
     {
         const GF256 &g = gf();
         uint8_t el[1024];
@@ -210,7 +216,11 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
     else if (k == "rx_fused" && v == "overlap") c->opt.rx_fused = 3;
     else if (k == "mfma_ring" && isnum && (num == 3 || num == 4)) c->opt.mfma_ring = (int)num;
     else if (k == "tx_overlap" && isnum && num <= 1) c->opt.tx_overlap = (int)num;
-    else if (k == "dec_path") {
+    else if (k == "enc_path") {
+        if (v == "fft") c->opt.enc_fft = 1;
+        else if (v == "karatsuba") c->opt.enc_fft = 0;
+        else return fail(SDRHIP_EINVAL, "ctx_set_option: enc_path must be fft or karatsuba");
+    } else if (k == "dec_path") {
         if (v == "syndrome") c->opt.dec_syndrome = 1;
         else if (v == "dense") c->opt.dec_syndrome = 0;
         else return fail(SDRHIP_EINVAL, "ctx_set_option: dec_path must be syndrome or dense");
@@ -244,6 +254,7 @@ static void sdrhip::ctx_free(sdrhip_ctx *c)
     if (c->gf_tab) (void)hipFree(c->gf_tab);
     if (c->enc_matrix) (void)hipFree(c->enc_matrix);
     if (c->enc_leaves) (void)hipFree(c->enc_leaves);
+    if (c->enc_fft) (void)hipFree(c->enc_fft);
     if (c->decim_dump) (void)hipFree(c->decim_dump);
     if (c->fused_roles) (void)hipFree(c->fused_roles);
     if (c->gf_explog) (void)hipFree(c->gf_explog);

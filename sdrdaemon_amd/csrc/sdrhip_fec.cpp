@@ -37,7 +37,7 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
         // the generic kernel come in groups of GF_FRAMES_PER_GROUP, this kernel takes them flat
         Enc128Args k;
         memset(&k, 0, sizeof(k));
-        k.in = frames; k.out = rec; k.tab = c->gf_tab; k.leaf_tables = c->enc_leaves;
+        k.in = frames; k.out = rec; k.tab = c->gf_tab; k.leaf_tables = c->enc_leaves; k.fft_tables = c->enc_fft; k.use_fft = c->opt.enc_fft;
         k.in_frame_bytes = frame_bytes; k.out_frame_bytes = rec_frame_bytes;
         k.rows = nb_fec; k.nframes = (int)nframes;
         k.frame_list = frame_list_dev; k.nlist = frame_list_dev ? ngroups * GF_FRAMES_PER_GROUP : (int)nframes;

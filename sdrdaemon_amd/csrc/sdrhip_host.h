@@ -122,6 +122,7 @@ struct CtxOptions {
     // decimator's launch (rx_fused_kernel), 3 = its own launch on the context's SECOND stream, beside the decimator ("overlap")
     int rx_fused = 1;
     int tx_overlap = 1;                    // pipelined Tx pipe: 1 = decode of this batch on the second stream beside the interpolator of the previous one, 0 = one stream
+    int enc_fft = 1;                       // structured 128-original encoder, rows <= 32: additive FFT (1) or the Karatsuba XOR-convolution walk (0)
     int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)
     int dec_strict = 0;                    // batched decode delivers only what the reference's copy-back loop delivers (SDRdaemonFECBuffer.cpp:204-211)
     int dec_max_rows = 128;                // upper bound of the recovery blocks a received frame can have used (the sender's fecblk)
@@ -150,6 +151,7 @@ struct sdrhip_ctx {
     uint8_t *gf_tab = nullptr;               // 256 x 32 B multiplier tables (device)
     uint8_t *enc_matrix = nullptr;           // 128 x 128 encode matrix, rows 128..255 (device)
     uint8_t *enc_leaves = nullptr;           // Karatsuba leaf tables of the structured k = 128 encoder (device)
+    uint8_t *enc_fft = nullptr;              // constants of the additive-FFT form of the same encoder (device)
     unsigned *decim_dump = nullptr;          // sink of the matrix-core decimator's warm-up stores (DecimArgs::mf_dump)
     unsigned *fused_roles = nullptr;         // role table of the fused Rx launch (rx_fused_kernel), fused_tag = its launch counter
     unsigned fused_tag = 0;

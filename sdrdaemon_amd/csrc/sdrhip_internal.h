@@ -221,6 +221,8 @@ struct Enc128Args {
     uint8_t *out;
     const uint8_t *tab;             // 256 x 32 byte multiplier tables (device)
     const uint8_t *leaf_tables;     // [8][81][32] multiplier tables of the Karatsuba leaves of G_0..G_7 (device)
+    const uint8_t *fft_tables;      // [192][32] butterfly / fold / row constants of the additive-FFT encoder (gf_encode128_fft.h, device)
+    int use_fft;                    // 1: rows <= 32 run the additive-FFT encoder (context option enc_path), 0: the Karatsuba walk
     size_t in_frame_bytes, out_frame_bytes;
     int rows;                       // recovery blocks, 1..128
     int nframes;                    // frames addressable through in/out

@@ -535,7 +535,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     if (done && R > 0) {
         if (structured) {
             // structured encoder, one workgroup per (frame, half block); frame (s, f) of the window is frame s * cap_frames + f
-            k.in = work; k.out = work + (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE; k.tab = c->gf_tab; k.leaf_tables = c->enc_leaves;
+            k.in = work; k.out = work + (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE; k.tab = c->gf_tab; k.leaf_tables = c->enc_leaves; k.fft_tables = c->enc_fft; k.use_fft = c->opt.enc_fft;
             k.in_frame_bytes = frame_bytes; k.out_frame_bytes = frame_bytes;
             k.rows = R; k.nframes = (int)((size_t)S * rx->cap_frames);
             k.nlist = (int)((size_t)S * done); k.gen_done = (int)done; k.gen_cap = (int)rx->cap_frames;
