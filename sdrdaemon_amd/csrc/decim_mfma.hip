@@ -127,13 +127,21 @@ struct MfConst {
     unsigned selB;  // the other lanes keep `old`
 };
 
-struct MfOut {
-    unsigned *p;          // where this lane's next four outputs go
+// FR = false: stream-order output; FR = true: UDPSinkFEC::write's frame layout (UDPSinkFEC.cpp:134-155), DecimArgs::frame_mode
+template <bool FR> struct MfOut {
+    unsigned *p;          // stream order: where this lane's next two outputs go
     unsigned *dump;       // 16 bytes per lane that swallow the stores of the warm-up period (no branch in the loop body)
     int store;            // 0 during warm-up
     int norm, trunk;
+    unsigned sel_pack;    // v_perm selector {own, received} -> {I, Q} halves of an output dword
+    // frame layout: the lane's next two samples sit at byte `off` (+ 4) of the stream's frame area unless they lie beyond the end
+    // of super block 1 + b (column c of the lane pair's first sample >= t0 / t1): then `extra` bytes further
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned off, c, b, t0, t1;
+    unsigned gap;         // bytes from the last sample of a frame to the first one of the next, minus 4
 };
 
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int sbfe16(unsigned v, int off) { return (int)__builtin_amdgcn_sbfe((int)v, (unsigned)off, 16u); }
 
 // (a << sh) + b = one v_lshl_add_u32.  Plain C on purpose: the operands come straight out of MFMAs and go into MFMAs,
@@ -157,7 +165,7 @@ __host__ __device__ constexpr int mf_nfixed(int ns) { return ns > 4 ? ns - 4 : 0
 __host__ __device__ constexpr bool mf_fixed(int ns, int s) { return s >= ns - mf_nfixed(ns); } // stage s of ns has a fixed window
 template <int NS> constexpr int mf_period() { return 4 << (NS - 1 - mf_nfixed(NS)); } // first-stage steps per period
 
-template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState<NS> &st, const MfConst &k, MfOut &oc, int comp)
+template <int NS, int S, int I, class OC> __device__ __forceinline__ void mf_stage(MfState<NS> &st, const MfConst &k, OC &oc, int comp)
 {
     // (the last stages of the long cascades keep their windows in fixed dwords, see mf_nfixed)
     constexpr int PH = mf_fixed(NS, S) ? 0 : (I & 3);
@@ -220,23 +228,55 @@ template <int NS, int S, int I> __device__ __forceinline__ void mf_stage(MfState
             st.O[S + 1][0][DN] = (int)e0; st.O[S + 1][1][DN] = (int)e1; st.O[S + 1][2][DN] = (int)e2;
         }
     } else {
-        // lanes n = 2p (I) and 2p + 1 (Q) hold the same outputs: both pack the same dwords and store them to the
-        // same place (no divergence, no branch: the loop body stays one basic block and hipcc's vmcnt waits stay
-        // exact); the warm-up period stores into the dump slot
-        unsigned pk[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = (int)acc[r] >> 13;
-            const int other = __builtin_amdgcn_update_dpp(0, o, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
-            pk[r] = final_pack(comp ? other : o, comp ? o : other, oc.norm, oc.trunk);
+        // Lanes n = 2p (I) and 2p + 1 (Q) hold the two components of the same four outputs.  The I lane finishes outputs 0, 1, the Q
+        // lane outputs 2, 3: each hands the other the two values it needs (one DPP move each), shifts its own two and the received
+        // two, and one v_perm with a lane-constant selector makes the {I, Q} dword.  (Until round 5 both lanes packed and stored all
+        // four dwords: twice the shifts and selects, 40 instructions per tile instead of 20.)  No divergence, no branch: the loop
+        // body stays one basic block and hipcc's vmcnt waits stay exact.
+        const int o0 = (int)acc[0] >> 13, o1 = (int)acc[1] >> 13, o2 = (int)acc[2] >> 13, o3 = (int)acc[3] >> 13;
+        const int g0 = comp ? o0 : o2, g1 = comp ? o1 : o3; // for the neighbour
+        const int m0 = comp ? o2 : o0, m1 = comp ? o3 : o1; // mine
+        const int r0 = __builtin_amdgcn_update_dpp(0, g0, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, true);
+        const int r1 = __builtin_amdgcn_update_dpp(0, g1, 0xB1, 0xf, 0xf, true);
+        // `x << norm_shift >> trunk_shift` then FixReal truncation, Decimators.cpp:112-113 (final_pack)
+        const unsigned pk0 = perm((unsigned)((int)((unsigned)r0 << oc.norm) >> oc.trunk), (unsigned)((int)((unsigned)m0 << oc.norm) >> oc.trunk), oc.sel_pack);
+        const unsigned pk1 = perm((unsigned)((int)((unsigned)r1 << oc.norm) >> oc.trunk), (unsigned)((int)((unsigned)m1 << oc.norm) >> oc.trunk), oc.sel_pack);
+        if constexpr (std::is_same<OC, MfOut<true>>::value) {
+            // frame layout: 127 samples per super block behind a 4-byte header, 127 blocks per frame behind the meta block.  A
+            // sample beyond the end of the block lies `extra` bytes further (the next block's header; from the last block on: the
+            // recovery blocks, the next frame's meta block and header).  Warm-up: `bias` puts the offsets beyond the descriptor's
+            // range, the hardware drops the stores.
+            const unsigned extra = oc.b == 126u ? oc.gap : 4u;
+            const unsigned bias = oc.store ? 0u : 0x80000000u;
+            // The lane's two samples go out as ONE 8-byte store (lane pairs then write 16 contiguous bytes, a tile 64 per span)
+            // unless the block ends between them (column c == t1, once in 127 samples): then as two 4-byte stores.  All three stores
+            // are always issued -- no branch -- with bit 30 of the offset set on the ones that do not apply: beyond the descriptor's
+            // range (1 GiB) like the warm-up's, the hardware drops them.  (First version: two 4-byte stores per lane -- every store
+            // instruction wrote every other dword of its 64-byte pieces: the launch took 243 us instead of 224, profiles/r05_rx_direct.txt.)
+            const unsigned a0 = oc.off + (oc.c >= oc.t0 ? extra : 0u) + bias;
+            const unsigned hi = a0 ^ 0x40000000u;
+            const bool split = oc.c == oc.t1;
+            const unsigned a8 = split ? hi : a0, a4 = split ? a0 : hi;
+            __builtin_amdgcn_raw_buffer_store_b64((uint2_t){pk0, pk1}, oc.rsrc, a8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(pk0, oc.rsrc, a4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(pk1, oc.rsrc, a4 + extra, 4, 0);
+            // the lane pair's next four outputs are 16 samples on
+            const unsigned inc = oc.store ? 16u : 0u;
+            oc.c += inc;
+            const bool wrap = oc.c >= 127u;
+            oc.off += 4u * inc + (wrap ? extra : 0u);
+            oc.c -= wrap ? 127u : 0u;
+            oc.b += wrap ? 1u : 0u;
+            oc.b = oc.b >= 127u ? 0u : oc.b;
+        } else {
+            // (Stored as they come a tile is 64 bytes per span.  On the memory skeleton of this kernel those 67 MB of
+            // scattered writes cost as much as 250 MB of reads although the same stores ALONE take 0.01 ms (tools/dma_probe.hip): it
+            // is the mix of the write stream with 5 TB/s of reads, not the granularity -- pairing two tiles into one 128-byte store
+            // changed nothing: tools/experiments_r03/decim_mfma_experiments.patch, MF_PAIR.)
+            unsigned *dst = oc.store ? oc.p : oc.dump;
+            *reinterpret_cast<uint2_t *>(dst) = (uint2_t){pk0, pk1};
+            oc.p += oc.store ? 16 : 0;
         }
-        // (Stored as they come a tile is 64 bytes per span, written twice.  On the memory skeleton of this kernel those 67 MB of
-        // scattered writes cost as much as 250 MB of reads although the same stores ALONE take 0.01 ms (tools/dma_probe.hip): it
-        // is the mix of the write stream with 5 TB/s of reads, not the granularity -- pairing two tiles into one 128-byte store
-        // changed nothing: tools/experiments_r03/decim_mfma_experiments.patch, MF_PAIR.)
-        unsigned *dst = oc.store ? oc.p : oc.dump;
-        *reinterpret_cast<uint4_t *>(dst) = (uint4_t){pk[0], pk[1], pk[2], pk[3]};
-        oc.p += oc.store ? 16 : 0;
     }
 }
 
@@ -327,8 +367,8 @@ template <int N> __device__ __forceinline__ void mf_wait_vm()
 // rotate by 4 % NG (NG = 4: not at all, NG = 3: by one -- three s_mov + three v_mov per 32 steps).  Step i issues the DMA of
 // group i / 8 + NG - 1, span i % 8 into the slot group i / 8 - 1 has just left; the group read next is awaited once per 8 steps:
 // behind its last DMA the wave has issued the NG - 3 + 1 full groups in between and 7 DMAs of the current issue group.
-template <int NS, int NG>
-__device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st, const MfConst &k, MfOut &oc, MfFront &fr, unsigned lds_addr,
+template <int NS, int NG, class OC>
+__device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st, const MfConst &k, OC &oc, MfFront &fr, unsigned lds_addr,
                                             const char *wbase, size_t S, int nper, int WP, int lane, int p, int comp, int q)
 {
     constexpr int P = mf_period<NS>();
@@ -401,7 +441,7 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
     mf_wait_vm<0>(); // no DMA may outlive the workgroup's LDS allocation
 }
 
-template <int NS, int NG = 0> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, unsigned lds_addr) // NG = 0: register ring
+template <int NS, int NG = 0, bool FR = false> __device__ __forceinline__ void mf_wave(const DecimArgs &a, int gw, unsigned lds_addr) // NG = 0: register ring
 {
     // beside another kernel's waves (overlap mode) the matrix-core wave is the one the launch waits for: it issues first
     if (a.mf_prio) __builtin_amdgcn_s_setprio(3);
@@ -444,14 +484,31 @@ template <int NS, int NG = 0> __device__ __forceinline__ void mf_wave(const Deci
     k.selA = q == 0 ? 0x03020104u : 0x03020100u;
     k.selB = q == 0 ? 0x03020106u : 0x03020100u;
 
-    MfOut oc;
+    MfOut<FR> oc;
     oc.store = 0;
     oc.dump = a.mf_dump + 4 * lane;
     oc.norm = a.norm; oc.trunk = a.trunk;
+    oc.sel_pack = comp ? 0x01000504u : 0x05040100u;
     {
-        unsigned *obase = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
-        const size_t first = ((wave_start + (size_t)p * S) >> L) + 4u * (unsigned)q; // this lane's first output
-        oc.p = obase + first;
+        // this lane's first output: the I lane of a pair finishes outputs 4q, 4q + 1 of a tile, the Q lane 4q + 2, 4q + 3
+        const size_t first = ((wave_start + (size_t)p * S) >> L) + 4u * (unsigned)q;
+        if constexpr (FR) {
+            // a.out = the stream's first frame slot, a.out_stride its pitch in dwords (DecimArgs::frame_mode)
+            unsigned *obase = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
+            oc.rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0x3fffffff, 0x00020000);
+            const unsigned long long g = a.frame_sample_base + first;
+            const unsigned long long f = g / 16129u;
+            const unsigned w = (unsigned)(g - f * 16129u);
+            oc.b = w / 127u; oc.c = w - oc.b * 127u;
+            oc.off = 4u * (unsigned)(((size_t)f * (size_t)a.frame_blocks + 1u + oc.b) * 128u + 1u + oc.c + 2u * (unsigned)comp);
+            oc.t0 = 127u - 2u * (unsigned)comp; oc.t1 = 126u - 2u * (unsigned)comp;
+            oc.gap = 4u * ((unsigned)a.frame_blocks * 128u - 16255u);
+            oc.p = nullptr;
+        } else {
+            unsigned *obase = reinterpret_cast<unsigned *>(a.out) + (size_t)stream * a.out_stride;
+            oc.p = obase + first + 2 * comp;
+            oc.off = oc.c = oc.b = oc.t0 = oc.t1 = oc.gap = 0u;
+        }
     }
 
     MfState<NS> st;
@@ -504,7 +561,7 @@ template <int NS, int NG = 0> __device__ __forceinline__ void mf_wave(const Deci
 // workgroups (head + tail pieces of every stream)
 __host__ __device__ constexpr int mf_block_threads(int) { return NT; }
 
-template <int L, bool PACK16, int NG> __global__ __launch_bounds__(mf_block_threads(L), mf_dma_applies(L) ? 1 : MF_WAVES) void decim_mfma_kernel(DecimArgs a)
+template <int L, bool PACK16, int NG, bool FR> __global__ __launch_bounds__(mf_block_threads(L), mf_dma_applies(L) ? 1 : MF_WAVES) void decim_mfma_kernel(DecimArgs a)
 {
     // the VALU pieces' stage buffers, or (matrix-core workgroups of the long cascades) the four waves' LDS-DMA rings
     constexpr int LDSDW = mf_dma_applies(L) && mf_wave_ring(NG) > DecimLds<L, 2, PACK16>::dwords ? mf_wave_ring(NG) : DecimLds<L, 2, PACK16>::dwords; // (4 waves x ring bytes / 4)
@@ -540,7 +597,7 @@ template <int L, bool PACK16, int NG> __global__ __launch_bounds__(mf_block_thre
     }
     const int gw = __builtin_amdgcn_readfirstlane(bx * 4 + (int)(threadIdx.x >> 6));
     if (gw >= a.nstreams * a.mf_wps) return;
-    mf_wave<L, NG>(a, gw, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds);
+    mf_wave<L, NG, FR>(a, gw, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds);
 }
 
 // ---- fused Rx launch: the decimator of THIS call and the CM256 encoder of the frames the PREVIOUS call completed, in one grid.
@@ -623,21 +680,28 @@ template <int L> hipError_t launch_fused(bool pack16, const DecimArgs &a, const 
     return hipGetLastError();
 }
 
+template <int L, int NG, bool FR> void launch_mf2(bool pack16, const DecimArgs &a, dim3 grid, dim3 block, hipStream_t stream)
+{
+    if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true, NG, FR>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((decim_mfma_kernel<L, false, NG, FR>), grid, block, 0, stream, a);
+}
+
 template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream_t stream)
 {
     const int nleg = a.mf_piece_wgs > 0 ? a.mf_piece_wgs : a.nstreams * a.mf_npieces;
     const int nmf = (a.nstreams * a.mf_wps + 3) / 4;
     const dim3 grid(nleg + nmf), block(mf_block_threads(L));
-    // ring depth: only the LDS-DMA kernel (decimate16) has one, and only it comes in both depths (DecimArgs::mf_ring)
+    // ring depth: only the LDS-DMA kernel (decimate16) has one, and only it comes in both depths (DecimArgs::mf_ring);
+    // frame_mode: the matrix-core waves store in the frame layout like the VALU pieces beside them
     if constexpr (mf_dma_applies(L)) {
         if (a.mf_ring == 3) {
-            if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true, 3>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((decim_mfma_kernel<L, false, 3>), grid, block, 0, stream, a);
+            if (a.frame_mode) launch_mf2<L, 3, true>(pack16, a, grid, block, stream);
+            else launch_mf2<L, 3, false>(pack16, a, grid, block, stream);
             return hipGetLastError();
         }
     }
-    if (pack16) hipLaunchKernelGGL((decim_mfma_kernel<L, true, 4>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((decim_mfma_kernel<L, false, 4>), grid, block, 0, stream, a);
+    if (a.frame_mode) launch_mf2<L, 4, true>(pack16, a, grid, block, stream);
+    else launch_mf2<L, 4, false>(pack16, a, grid, block, stream);
     return hipGetLastError();
 }
 

@@ -32,11 +32,14 @@
 #pragma once
 
 constexpr int FFT_NTAB = 192;                       // gf256.h: CM256_FFT_TABLES
-constexpr int FFT_TAB_BYTES = FFT_NTAB * 20;        // {Ta, Tb} 16 B + {Tc} 4 B per table
+constexpr int FFT_TAB_BYTES = FFT_NTAB * 32;        // the 32-byte records of gf_build_tables as they are: {Ta, Tb} 16 B, {Tc} 4 B, 12 B unused (ONE address register)
 // + per column half 32 x 64 dwords of exchange (e_lo down, rows 0..15 back up) and 2 x 64 of parity
 constexpr int FFT_XCH_DWORDS = 32 * 64 + 2 * 64;
 constexpr int ENC128_FFT_LDS_BYTES = FFT_TAB_BYTES + 2 * FFT_XCH_DWORDS * 4;
 constexpr int FFT_MAX_ROWS = 32;
+#ifndef FFT_WAVES_PER_EU
+#define FFT_WAVES_PER_EU 5 // 96 registers: five workgroups per CU hold all 1040 + K2's workgroups of the headline step at once
+#endif
 #ifndef FFT_SKIP_ZERO
 #define FFT_SKIP_ZERO 0
 #endif
@@ -50,10 +53,10 @@ struct FftTabs {
     uint4_t t[2];
     unsigned c[2];
 };
-template <int P, int IDX> __device__ __forceinline__ void fft_issue(FftTabs &R, unsigned la16, unsigned la4)
+template <int P, int IDX> __device__ __forceinline__ void fft_issue(FftTabs &R, unsigned la)
 {
-    asm volatile("ds_read_b128 %0, %2 offset:%c4\n\tds_read_b32 %1, %3 offset:%c5"
-                 : "=&v"(R.t[P]), "=&v"(R.c[P]) : "v"(la16), "v"(la4), "i"(IDX * 16), "i"(IDX * 4) : "memory");
+    asm volatile("ds_read_b128 %0, %2 offset:%c3\n\tds_read_b32 %1, %2 offset:%c4"
+                 : "=&v"(R.t[P]), "=&v"(R.c[P]) : "v"(la), "i"(IDX * 32), "i"(IDX * 32 + 16) : "memory");
 }
 template <int P> __device__ __forceinline__ void fft_wait(FftTabs &R)
 {
@@ -71,6 +74,15 @@ template <int P> __device__ __forceinline__ void fft_muladd(unsigned &a, unsigne
     asm volatile("" : "+v"(a));
 }
 
+// the lane's index in its wave, formed anew wherever it is called (the opaque zero keeps the calls apart): what follows from it --
+// column, lane offset, exchange address -- need not stay in registers across the transform (they were the kernel's last spills)
+__device__ __forceinline__ unsigned fft_lane()
+{
+    unsigned z = 0u;
+    asm volatile("" : "+v"(z));
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+}
+
 template <class F, int... Is> __device__ __forceinline__ void fft_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void fft_for(F &&f) { fft_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
@@ -78,16 +90,16 @@ template <int N, class F> __device__ __forceinline__ void fft_for(F &&f) { fft_f
 __host__ __device__ constexpr int fft_inv_stage(int n) { int k = 0; while (n >= 64 - (64 >> (k + 1))) ++k; return k; }
 
 // inverse transform of size 64 (values on the coset 64 hf + V6 -> novel-basis coefficients) and the t5 fold: d[0..31] = the half's
-// 32 coefficients on 128 + V5.  lh16 / lh4: table 0 of this half; la16 / la4: table 0.
-__device__ __forceinline__ void fft_inverse64_fold(unsigned (&d)[64], int hf, unsigned lh16, unsigned lh4, unsigned la16, unsigned la4)
+// 32 coefficients on 128 + V5.  lh: LDS address of table 0 of this half; la: of table 0.
+__device__ __forceinline__ void fft_inverse64_fold(unsigned (&d)[64], int hf, unsigned lh, unsigned la)
 {
     FftTabs R;
-    fft_issue<0, 0>(R, lh16, lh4);
+    fft_issue<0, 0>(R, lh);
     fft_for<63>([&](auto nc) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value, k = fft_inv_stage(n), h = 1 << k, j = n - (64 - (64 >> k)), blk = j * 2 * h, P = n & 1;
         fft_wait<P>(R);
-        if constexpr (n + 1 < 63) fft_issue<P ^ 1, n + 1>(R, lh16, lh4);
-        else fft_issue<P ^ 1, 126>(R, la16, la4); // t5
+        if constexpr (n + 1 < 63) fft_issue<P ^ 1, n + 1>(R, lh);
+        else fft_issue<P ^ 1, 126>(R, la); // t5
 #pragma unroll
         for (int i = 0; i < h; ++i) d[blk + h + i] ^= d[blk + i];
         // (the leading block of a stage sits on the coset representative 64 hf: s^_k(0) = 0, nothing to multiply in the first half)
@@ -103,13 +115,12 @@ __device__ __forceinline__ void fft_inverse64_fold(unsigned (&d)[64], int hf, un
 
 // rows 16 hh .. 16 hh + 15 of the size-32 transform on 128 + V5 behind its first stage: stages 3..0 on 16 values; the tables of
 // stage k are 128 + (32 - (32 >> k)) + (8 >> k) hh + j.
-__device__ __forceinline__ void fft_forward16(unsigned (&e)[16], int hh, unsigned la16, unsigned la4)
+__device__ __forceinline__ void fft_forward16(unsigned (&e)[16], int hh, unsigned la)
 {
     FftTabs R;
     // blocks in order: n = 0 (k = 3), 1..2 (k = 2), 3..6 (k = 1), 7..14 (k = 0)
-    auto base16 = [&](int k) { return la16 + (unsigned)hh * (unsigned)((8 >> k) * 16); };
-    auto base4 = [&](int k) { return la4 + (unsigned)hh * (unsigned)((8 >> k) * 4); };
-    fft_issue<0, 128 + 32 - 4>(R, base16(3), base4(3));
+    auto base = [&](int k) { return la + (unsigned)hh * (unsigned)((8 >> k) * 32); };
+    fft_issue<0, 128 + 32 - 4>(R, base(3));
     fft_for<15>([&](auto nc) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value;
         constexpr int k = n < 1 ? 3 : n < 3 ? 2 : n < 7 ? 1 : 0;
@@ -118,7 +129,7 @@ __device__ __forceinline__ void fft_forward16(unsigned (&e)[16], int hh, unsigne
         fft_wait<P>(R);
         if constexpr (n + 1 < 15) {
             constexpr int n1 = n + 1, k1 = n1 < 1 ? 3 : n1 < 3 ? 2 : n1 < 7 ? 1 : 0, j1 = n1 - ((8 >> k1) - 1);
-            fft_issue<P ^ 1, 128 + 32 - (32 >> k1) + j1>(R, base16(k1), base4(k1));
+            fft_issue<P ^ 1, 128 + 32 - (32 >> k1) + j1>(R, base(k1));
         }
 #pragma unroll
         for (int i = 0; i < h; ++i) {
@@ -128,16 +139,21 @@ __device__ __forceinline__ void fft_forward16(unsigned (&e)[16], int hh, unsigne
     });
 }
 
+#ifdef FFT_STAMPS
+// timeline experiment (tools/experiments_r05/fft_stamps.py): lane 0 of every wave of the first 2048 workgroups leaves s_memrealtime
+// (100 MHz) at six points + HW_ID
+__device__ unsigned long long g_fft_stamps[8192 * 8];
+#define FFT_STAMP(k) do { if (blockIdx.x < 2048 && (threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_fft_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
+#else
+#define FFT_STAMP(k) do { } while (0)
+#endif
+
 // the workgroup's tables: global (32-byte records) -> LDS {16 B} + {4 B} arrays.  All threads; a barrier follows.
 __device__ __forceinline__ void fft_fill_tables(const Enc128Args &a, unsigned char *ldsraw)
 {
-    uint4_t *lt16 = reinterpret_cast<uint4_t *>(ldsraw);
-    unsigned *lt4 = reinterpret_cast<unsigned *>(ldsraw + FFT_NTAB * 16);
-    for (int i = threadIdx.x; i < FFT_NTAB; i += GF_NT) {
-        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables) + (size_t)i * 2;
-        lt16[i] = src[0];
-        lt4[i] = reinterpret_cast<const unsigned *>(src + 1)[0];
-    }
+    uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
+    const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables);
+    for (int i = threadIdx.x; i < 2 * FFT_NTAB; i += GF_NT) lt[i] = src[i];
     __syncthreads();
 }
 
@@ -145,11 +161,13 @@ __device__ __forceinline__ void fft_fill_tables(const Enc128Args &a, unsigned ch
 // place, fused framing copy) is gf_encode128_wg's, block for block.
 __device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi, unsigned char *ldsraw)
 {
+    FFT_STAMP(0);
     fft_fill_tables(a, ldsraw);
-    const unsigned la16 = lds_addr(ldsraw), la4 = lds_addr(ldsraw + FFT_NTAB * 16);
+    FFT_STAMP(1);
+    const unsigned la = lds_addr(ldsraw);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ch = wv & 1, hf = wv >> 1;
-    const int lane = threadIdx.x & 63;
+    const int lane = (int)fft_lane();
     const int fr = a.gen_done > 0 ? (fi / a.gen_done) * a.gen_cap + fi % a.gen_done : (a.frame_list ? __builtin_amdgcn_readfirstlane(a.frame_list[fi]) : fi);
     if (fr < 0 || fr >= a.nframes) return; // (workgroup-uniform: all four waves leave in front of the barriers below)
     const int col = ch * 64 + lane;
@@ -194,7 +212,7 @@ __device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi,
             sbase = a.lin + (size_t)s * a.lin_stride;
         }
     }
-    unsigned *xch = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES) + ch * FFT_XCH_DWORDS + lane; // [i][lane], i < 32; parity at [32], [33]
+    unsigned *const xch0 = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES) + ch * FFT_XCH_DWORDS; // [i][lane], i < 32; parity at [32], [33]
 
     // ONE load sequence for both sources (descriptor and block pitch are picked once, uniformly): two sequences that define the
     // same 64 registers met in a join the register allocator answered with a few hundred moves and spills
@@ -234,54 +252,61 @@ __device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi,
 #pragma unroll
         for (int i = 0; i < 64; ++i) __builtin_amdgcn_raw_buffer_store_b32(d[i], rf, lc4, (b0 + i) * 512, 0);
     }
-    unsigned par = 0u;
+    {
+        unsigned par = 0u;
 #pragma unroll
-    for (int i = 0; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
-    fft_inverse64_fold(d, hf, la16 + (unsigned)(hf * 63 * 16), la4 + (unsigned)(hf * 63 * 4), la16, la4);
+        for (int i = 0; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
+        (xch0 + lane)[(32 + hf) * 64] = par; // (both halves' parities wait in LDS: one long-lived register less)
+    }
+    FFT_STAMP(2);
+    fft_inverse64_fold(d, hf, la + (unsigned)(hf * 63 * 32), la);
+    FFT_STAMP(3);
 
     unsigned e[16];
+    unsigned *const xch = xch0 + fft_lane();
     if (hf == 0) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) xch[i * 64] = d[i];
-        xch[32 * 64] = par;
     }
     __syncthreads();
     if (hf != 0) {
+        // t6 and the one block of stage 4, rows i and 16 + i together: the pair is finished (row i parked for the other wave, row
+        // 16 + i kept) before the next one is read -- 64 + 16 live values instead of 96
         FftTabs R;
-        fft_issue<0, 127>(R, la16, la4); // t6
-        unsigned lo[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) lo[i] = xch[i * 64];
-        par ^= xch[32 * 64];
-        fft_wait<0>(R); // (and the 33 reads above)
-        fft_issue<1, 128 + 32 - 2>(R, la16, la4); // the one block of stage 4
-#pragma unroll
-        for (int i = 0; i < 32; ++i) { d[i] ^= lo[i]; fft_muladd<0>(lo[i], d[i], R); }
+        fft_issue<0, 127>(R, la);           // t6
+        fft_issue<1, 128 + 32 - 2>(R, la);  // stage 4
+        fft_wait<0>(R);
         fft_wait<1>(R);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            fft_muladd<1>(lo[i], lo[16 + i], R);
-            e[i] = lo[16 + i] ^ lo[i];
-            xch[i * 64] = lo[i];
+            unsigned la = xch[i * 64], lb = xch[(16 + i) * 64];
+            d[i] ^= la; fft_muladd<0>(la, d[i], R);
+            d[16 + i] ^= lb; fft_muladd<0>(lb, d[16 + i], R);
+            fft_muladd<1>(la, lb, R);
+            e[i] = lb ^ la;
+            xch[i * 64] = la;
         }
-        xch[33 * 64] = par;
     }
     __syncthreads();
     if (hf == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) e[i] = xch[i * 64];
-        par = xch[33 * 64];
     }
-    fft_forward16(e, hf, la16, la4);
+    FFT_STAMP(4);
+    fft_forward16(e, hf, la);
     // rows 16 hf + i
     {
         FftTabs R;
-        const unsigned k16 = la16 + (unsigned)hf * 256u, k4 = la4 + (unsigned)hf * 64u;
-        fft_issue<0, 160>(R, k16, k4);
+        const unsigned ln = fft_lane(), col = (unsigned)ch * 64u + ln;
+        const bool live = col < 127u;
+        const unsigned lc = live ? col : 126u, lc4 = 4u * lc;
+        const unsigned par = (xch0 + ln)[32 * 64] ^ (xch0 + ln)[33 * 64];
+        const unsigned lk = la + (unsigned)hf * 512u;
+        fft_issue<0, 160>(R, lk);
         fft_for<16>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::value, P = i & 1;
             fft_wait<P>(R);
-            if constexpr (i + 1 < 16) fft_issue<P ^ 1, 160 + i + 1>(R, k16, k4);
+            if constexpr (i + 1 < 16) fft_issue<P ^ 1, 160 + i + 1>(R, lk);
             const int r = 16 * hf + i;
             if (r < a.rows && live) {
                 unsigned v = par;
@@ -292,7 +317,14 @@ __device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi,
             }
         });
     }
+    FFT_STAMP(5);
+#ifdef FFT_STAMPS
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_fft_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 6] = hw; }
+#endif
 }
 
-constexpr int ENC128_FFT_KERNEL_LDS = ENC128_FFT_LDS_BYTES;
+#ifndef FFT_LDS_PAD
+#define FFT_LDS_PAD 0 // (experiment: extra bytes of LDS per workgroup = fewer workgroups per CU)
+#endif
+constexpr int ENC128_FFT_KERNEL_LDS = ENC128_FFT_LDS_BYTES + FFT_LDS_PAD;
 __device__ __forceinline__ void gf_encode128_fft_unit(const Enc128Args &a, int fi, unsigned char *ldsraw) { gf_encode128_fft_wg(a, fi, ldsraw); }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(GF_NT, 4) void gf_encode128_kernel(Enc128Args a) //
 
 // the additive-FFT encoder (rows <= 32): a workgroup per frame
 #include "gf_encode128_fft.h"
-__global__ __launch_bounds__(GF_NT, 4) void gf_encode128_fft_kernel(Enc128Args a)
+__global__ __launch_bounds__(GF_NT, FFT_WAVES_PER_EU) void gf_encode128_fft_kernel(Enc128Args a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char ldsraw[ENC128_FFT_KERNEL_LDS];
     gf_encode128_fft_unit(a, (int)blockIdx.x, ldsraw);
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(GF_NT, 4) void gf_encode128_pack_kernel(Enc128Args 
     }
 }
 // ... with the additive-FFT encoder: nlist encoder workgroups in front of K2's
-__global__ __launch_bounds__(GF_NT, 4) void gf_encode128_fft_pack_kernel(Enc128Args a, FrameArgs f, unsigned pack_bx)
+__global__ __launch_bounds__(GF_NT, FFT_WAVES_PER_EU) void gf_encode128_fft_pack_kernel(Enc128Args a, FrameArgs f, unsigned pack_bx)
 {
     __shared__ __attribute__((aligned(16))) unsigned char ldsraw[ENC128_FFT_KERNEL_LDS];
     const unsigned nenc = (unsigned)a.nlist;
@@ -729,6 +729,9 @@ hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+#ifdef FFT_STAMPS
+extern "C" int sdrhip_debug_fft_stamps(unsigned long long *dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fft_stamps), sizeof(g_fft_stamps)); }
+#endif
 hipError_t launch_gf_encode128(const Enc128Args &a, hipStream_t stream)
 {
     if (a.nlist <= 0 || a.rows <= 0) return hipSuccess;

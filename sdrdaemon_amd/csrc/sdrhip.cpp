@@ -119,7 +119,7 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
         // the environment is read here, once (getenv is not safe against a concurrent setenv): later changes go through
         // sdrhip_ctx_set_option()
         static const char *const keys[][2] = {{"SDRHIP_DECIM_PATH", "decim_path"}, {"SDRHIP_MFMA_SPAN", "mfma_span"}, {"SDRHIP_MFMA_MIN", "mfma_min"},
-                                              {"SDRHIP_INTERP_PATH", "interp_path"}, {"SDRHIP_INTERP_SPAN", "interp_span"}, {"SDRHIP_RX_FUSED", "rx_fused"},
+                                              {"SDRHIP_INTERP_PATH", "interp_path"}, {"SDRHIP_INTERP_SPAN", "interp_span"}, {"SDRHIP_RX_FUSED", "rx_fused"}, {"SDRHIP_RX_DIRECT", "rx_direct"},
                                               {"SDRHIP_DEC_PATH", "dec_path"}, {"SDRHIP_ENC_PATH", "enc_path"}, {"SDRHIP_MFMA_RING", "mfma_ring"}, {"SDRHIP_TX_OVERLAP", "tx_overlap"}};
         for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); ++i)
             if (const char *v = getenv(keys[i][0])) (void)sdrhip_ctx_set_option(c, keys[i][1], v);
@@ -214,6 +214,7 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
     else if (k == "interp_span" && isnum) c->opt.interp_span = (size_t)num;
     else if (k == "rx_fused" && isnum && num <= 3) c->opt.rx_fused = (int)num;
     else if (k == "rx_fused" && v == "overlap") c->opt.rx_fused = 3;
+    else if (k == "rx_direct" && isnum && num <= 1) c->opt.rx_direct = (int)num;
     else if (k == "mfma_ring" && isnum && (num == 3 || num == 4)) c->opt.mfma_ring = (int)num;
     else if (k == "tx_overlap" && isnum && num <= 1) c->opt.tx_overlap = (int)num;
     else if (k == "enc_path") {
@@ -451,7 +452,9 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     // SDRHIP_DECIM_PATH = valu | mfma | auto (default), SDRHIP_MFMA_SPAN = span length in samples (tests)
     const CtxOptions &env = c->opt;
     bool use_mfma = false;
-    if (!frame_mode && env.decim_path != DECIM_PATH_VALU && (env.decim_path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= mfma_min_samples(env, (int)L)))
+    // (frame mode on the matrix cores: the waves' store offsets are 32 bits with the top two reserved, decim_mfma.hip)
+    const bool mfma_frames = env.rx_direct && out_stride * 4 < 0x3fffffffu;
+    if ((!frame_mode || mfma_frames) && env.decim_path != DECIM_PATH_VALU && (env.decim_path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= mfma_min_samples(env, (int)L)))
         use_mfma = plan_decimate_mfma((int)L, fcpos, a.n_used, d->nstreams, env.mfma_span, c->n_cu, &a);
     a.mf_dump = c->decim_dump;
     a.mf_ring = coresident ? 3 : env.mfma_ring;

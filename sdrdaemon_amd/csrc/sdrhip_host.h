@@ -121,6 +121,9 @@ struct CtxOptions {
     // pipelined Rx pipe, where the encoder of the previous call's frames runs: 0 = its own launch behind the decimator, 1 = inside the
     // decimator's launch (rx_fused_kernel), 3 = its own launch on the context's SECOND stream, beside the decimator ("overlap")
     int rx_fused = 1;
+    // Rx pipe on the matrix-core decimator: 1 = its waves store straight into the frame layout (round 5: no stream-order buffer, no
+    // framing copy in the encoder, no K2 launch), 0 = stream order + K2 + the encoder's fused copy (the round-3 arrangement)
+    int rx_direct = 1;
     int tx_overlap = 1;                    // pipelined Tx pipe: 1 = decode of this batch on the second stream beside the interpolator of the previous one, 0 = one stream
     int enc_fft = 1;                       // structured 128-original encoder, rows <= 32: additive FFT (1) or the Karatsuba XOR-convolution walk (0)
     int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)

@@ -418,7 +418,12 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         const bool wrap_hits_late = late_here && need > rx->late.slot0; // the wrapped window [0, need) against [slot0, slot0 + frames)
         if (need > rx->cap_frames || wrap_hits_late) {
             DevBuf bigger;
-            const size_t ncap = need > rx->cap_frames ? 4 * need : rx->cap_frames;
+            // the window: TWO calls' frames (round 5; four until then).  The step rewrites what it wrote two calls ago: 2 x 84 MB per
+            // 8-stream bank stay in the 256 MB of Infinity Cache, and on this memory system a write stream that stays there
+            // costs the read stream beside it less (profiles/r05_rx_window.txt: decimator launch 0.2435 -> 0.2335 ms, encoder
+            // launch 0.052 -> 0.049 ms; a window of one call wraps -- a copy of the open frames -- on every call).  SDRHIP_RX_WINDOW = A / B
+            static const size_t wmul = getenv("SDRHIP_RX_WINDOW") ? (size_t)atoi(getenv("SDRHIP_RX_WINDOW")) : 2;
+            const size_t ncap = need > rx->cap_frames ? (wmul ? wmul : 1) * need : rx->cap_frames;
             if ((rc = bigger.reserve((size_t)S * ncap * frame_bytes))) return rc;
             if (rx->frame_open)
                 HIP_TRY(hipMemcpy2DAsync(bigger.p, ncap * frame_bytes, rx->work.as<uint8_t>() + rx->base_slot * frame_bytes,
@@ -483,7 +488,9 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     // leaves room on its CUs (ring depth 3) and raises its waves' priority
     const bool coresident = rx->late.encode && c->opt.rx_fused == 3 && rx->ev_framed;
     bool fused = false;
-    if (filterless || decimate_mfma_applies(rx->dec, L, rx->cfg.fcpos, n_in)) {
+    // (matrix-core decimator: stream order + K2 + the encoder's fused copy, unless its waves frame their output themselves)
+    const bool direct = c->opt.rx_direct && !rx->pipelined && stream_bytes < 0x3fffffffu;
+    if (filterless || (!direct && decimate_mfma_applies(rx->dec, L, rx->cfg.fcpos, n_in))) {
         // ---- decimate in stream order, then K2 lays the samples out as super blocks (+ meta blocks and headers)
         const size_t lstride = (n_dec + 3) & ~(size_t)3;
         if (rx->pipelined) rx->lin_sel ^= 1; // (the deferred encoder of the previous call still reads the other one)
@@ -521,7 +528,8 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
             if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "frame pack launch: %s", hipGetErrorString(e));
         }
     } else {
-        // ---- decimate straight into the frame layout (VALU cascade kernel with the framing epilogue)
+        // ---- decimate straight into the frame layout (VALU cascade kernel with the framing epilogue, or the matrix-core kernel
+        // with its frame-layout stores and the VALU pieces' epilogue for meta blocks and headers)
         rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, reinterpret_cast<int16_t *>(work), stream_bytes / 4, &n_out, 1,
                              FB, rx->pending_samples, &meta);
         if (rc) return rc;

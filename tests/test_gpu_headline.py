@@ -121,6 +121,36 @@ def test_headline_rx_fused_and_separate_launches(ctx, fused):
         ctx.set_option("rx_fused", 1)
 
 
+@pytest.mark.parametrize("direct,enc", [(0, "fft"), (1, "karatsuba"), (0, "karatsuba"), (1, "fft")])
+def test_headline_rx_arrangements(ctx, direct, enc):
+    """the Rx step's data paths (round 5): the matrix-core decimator storing straight into the frame layout (rx_direct 1) or in
+    stream order with K2 + the encoder's fused copy behind it (0), the CM256 encoder as additive FFT or as Karatsuba walk: the same
+    frames, bit for bit, in every combination -- two calls, so that the second one begins inside an open frame"""
+    import torch
+
+    x, b = _bank("bank8")
+    ctx.set_option("rx_direct", direct)
+    ctx.set_option("enc_path", enc)
+    try:
+        rx = _rx(ctx, x.shape[0])
+        view = rx.process_view(x, tv_sec=H["meta"]["tv_sec"], tv_usec=H["meta"]["tv_usec"])
+        ctx.synchronize()
+        _check_frames(view, b)
+        # a second, ragged pair of calls against one call of another pipe in the default arrangement
+        n1 = 16 * 70001
+        ra = _rx(ctx, x.shape[0])
+        fa = [ra.process_view(x[:, :n1], 1, 2).torch().clone(), ra.process_view(x[:, n1:2 * n1], 3, 4).torch().clone()]
+        ctx.set_option("rx_direct", 1); ctx.set_option("enc_path", "fft")
+        rb = _rx(ctx, x.shape[0])
+        fb = [rb.process_view(x[:, :n1], 1, 2).torch().clone(), rb.process_view(x[:, n1:2 * n1], 3, 4).torch().clone()]
+        ctx.synchronize()
+        for u, v in zip(fa, fb):
+            assert u.shape == v.shape and torch.equal(u, v)
+    finally:
+        ctx.set_option("rx_direct", 1)
+        ctx.set_option("enc_path", "fft")
+
+
 def test_headline_one_stream_2p27(ctx):
     """configs[2] literally: one stream of 2^27 samples through the decimator and through the Rx pipe, whole outputs"""
     import torch

@@ -59,7 +59,7 @@ if "interp" in what:
         print("interpolate%-2d_cen  %8.3f ms  %8.1f Gsamples/s out  %7.1f GB/s" % (1 << L, ms, go, go * (4 + 4 / (1 << L))))
         del x, out
 if "fec" in what:
-    F = 2048
+    F = int(os.environ.get("FEC_F", "2048"))
     frames = torch.randint(0, 256, (F, 128, 512), generator=g, device=dev, dtype=torch.uint8)
     frames[:, :, 2] = torch.arange(128, device=dev, dtype=torch.uint8)
     ms = timed(K_FEC_ENCODE, lambda: sd.fec_encode_frames(ctx, frames, 32))
