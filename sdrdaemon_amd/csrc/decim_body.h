@@ -323,18 +323,25 @@ __device__ __forceinline__ void decim_piece(const DecimArgs &a, int *lds, int st
 
     // fused Rx pipe: meta block + super block headers of the frames this call starts, one frame per
     // workgroup (frame i of the stream by segment i mod nseg); nothing else writes those dwords
-    if (a.frame_mode && tid < 128) {
-        for (int fi = meta_id; fi < a.meta_count; fi += meta_n) {
+    if (a.frame_mode) {
+        // (i) the 24-byte records, a frame per THREAD: two 64-bit divisions and a CRC each -- one frame at a time, with the record
+        // formed by a whole wave, this loop took ~1.2 us per frame, and the matrix-core launch leaves it to three workgroups per
+        // stream: 130 frames = the launch's tail (profiles/r05_rx_direct.txt); (ii) zero fill and block headers, a frame per pass
+        for (int fi = meta_id + tid * meta_n; fi < a.meta_count; fi += NT * meta_n) {
             unsigned w[6];
-            frame_meta_words(a.meta_w, a.meta_idx0, a.meta_rate, fi, w); // per-frame time stamp + CRC (wave-uniform)
-            unsigned mw = 0u; // dword tid of block 0 behind the header: the 24-byte MetaDataFEC, then zeros
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-                if (tid == k + 1) mw = w[k];
+            frame_meta_words_thread(a.meta_w, a.meta_idx0, a.meta_rate, fi, w);
             unsigned *fr = oc.out + (size_t)(a.meta_first + fi) * a.frame_blocks * 128u;
-            const unsigned fidx = (a.meta_frame_count0 + (unsigned)fi) & 0xffffu;
-            fr[tid] = tid == 0 ? fidx : mw; // block 0: 512 bytes = 128 dwords
-            if (tid >= 1) fr[(size_t)tid * 128] = fidx | ((unsigned)tid << 16);
+            fr[0] = (a.meta_frame_count0 + (unsigned)fi) & 0xffffu;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) fr[1 + k] = w[k];
+        }
+        if (tid < 128) {
+            for (int fi = meta_id; fi < a.meta_count; fi += meta_n) {
+                unsigned *fr = oc.out + (size_t)(a.meta_first + fi) * a.frame_blocks * 128u;
+                const unsigned fidx = (a.meta_frame_count0 + (unsigned)fi) & 0xffffu;
+                if (tid >= 7) fr[tid] = 0u; // block 0 behind the record: zeros (512 bytes = 128 dwords)
+                if (tid >= 1) fr[(size_t)tid * 128] = fidx | ((unsigned)tid << 16);
+            }
         }
     }
 

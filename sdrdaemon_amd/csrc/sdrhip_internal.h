@@ -120,6 +120,27 @@ __device__ __forceinline__ void frame_meta_words(const unsigned (&base)[6], uint
     for (int m = 32; m >= 1; m >>= 1) x ^= (unsigned)__shfl_xor((int)x, m, 64);
     w[5] = base[5] ^ x;
 }
+// the same record by ONE thread (no cross-lane step: every lane of a wave can form the record of a different frame at once)
+__device__ __forceinline__ void frame_meta_words_thread(const unsigned (&base)[6], uint64_t idx0, unsigned rate, int fi, unsigned (&w)[6])
+{
+    unsigned sec = base[3], usec = base[4];
+    if (rate) {
+        const uint64_t idx = idx0 + (uint64_t)fi * 16129u;
+        const uint64_t dus = idx * 1000000ull / rate;
+        const uint64_t ds = dus / 1000000ull;
+        usec += (unsigned)(dus - ds * 1000000ull);
+        sec += (unsigned)ds;
+        if (usec >= 1000000u) { usec -= 1000000u; sec += 1u; }
+    }
+    w[0] = base[0]; w[1] = base[1]; w[2] = base[2]; w[3] = sec; w[4] = usec;
+    unsigned x = 0u;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+        x ^= (0u - ((sec >> k) & 1u)) & CRC_BIT.c[k];
+        x ^= (0u - ((usec >> k) & 1u)) & CRC_BIT.c[32 + k];
+    }
+    w[5] = base[5] ^ x;
+}
 #endif
 
 // returns hipSuccess or the launch error

@@ -422,8 +422,10 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
             // 8-stream bank stay in the 256 MB of Infinity Cache, and on this memory system a write stream that stays there
             // costs the read stream beside it less (profiles/r05_rx_window.txt: decimator launch 0.2435 -> 0.2335 ms, encoder
             // launch 0.052 -> 0.049 ms; a window of one call wraps -- a copy of the open frames -- on every call).  SDRHIP_RX_WINDOW = A / B
-            static const size_t wmul = getenv("SDRHIP_RX_WINDOW") ? (size_t)atoi(getenv("SDRHIP_RX_WINDOW")) : 2;
-            const size_t ncap = need > rx->cap_frames ? (wmul ? wmul : 1) * need : rx->cap_frames;
+            // (pipelined pipes keep the previous call's frames until they are delivered: four calls, as before)
+            static const size_t wenv = getenv("SDRHIP_RX_WINDOW") ? (size_t)atoi(getenv("SDRHIP_RX_WINDOW")) : 0;
+            const size_t wmul = wenv ? wenv : rx->pipelined ? 4 : 2;
+            const size_t ncap = need > rx->cap_frames ? wmul * need : rx->cap_frames;
             if ((rc = bigger.reserve((size_t)S * ncap * frame_bytes))) return rc;
             if (rx->frame_open)
                 HIP_TRY(hipMemcpy2DAsync(bigger.p, ncap * frame_bytes, rx->work.as<uint8_t>() + rx->base_slot * frame_bytes,

@@ -9,7 +9,7 @@ import sdrdaemon_amd as sd
 import signals
 
 ctx = sd.Context(0)
-S, n = 8, 1 << 25
+S, n = int(os.environ.get("STREAMS", "8")), 1 << int(os.environ.get("LOG2N", "25"))
 x = torch.stack([signals.hash_noise_torch(n, 1000 + s, "cuda") for s in range(S)])
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
 
