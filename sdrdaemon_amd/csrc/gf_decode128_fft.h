@@ -1,0 +1,188 @@
+// gf_decode128_fft.h -- the syndrome decoder for 128 originals (gf_decode128_wg, gf_kernels.hip) with the additive-FFT encoder walk
+// (gf_encode128_fft.h) in place of the Karatsuba walk (round 5).  Include inside namespace sdrhip { namespace { ... } } behind
+// Dec128Plan / Dec128Args, gf_encode128_fft.h and mulc / make_sel.
+//
+// What the received originals contribute to the received recovery rows is what the ENCODER computes with the erased originals set
+// to zero (SDRdaemonFECBuffer.cpp:197's cm256_decode seen from the other side): syndrome_i = recovery_i ^ that, erased originals =
+// Minv (N x N, from the planner) x syndromes.  The encoder part is the size-128 inverse transform + fold + size-32 transform of
+// gf_encode128_fft.h: 592 constant multiplications per 4-byte column instead of 1296, for recovery rows 0..31 (a frame that holds a
+// higher row -- a sender with more than 32 FEC blocks -- takes the Karatsuba walk: gf_decode128_fft_unit).
+// A WORKGROUP is one frame, its four waves = (column half ch, block half hf) like the encoder's; Minv x syndromes: the two waves
+// of a column half share the N rows (rows t with t mod 4 in {hf, hf + 2}).
+#pragma once
+
+// LDS: FFT tables | all 256 multiplier tables (Minv's constants) | the frame's plan record | per column half [34][64] dwords of
+// exchange (fft_rows16 + two parity rows); the syndromes ([32][64] per column half) take the exchange rows' place behind a barrier
+constexpr int DEC128_FFT_LDS_BYTES = FFT_TAB_BYTES + 256 * 32 + DEC128_PLAN_BYTES + 2 * FFT_XCH_DWORDS * 4;
+static_assert(DEC128_PLAN_BYTES % 16 == 0 && DEC128_MAXN == 32, "plan record layout");
+
+__device__ __forceinline__ void gf_decode128_fft_wg(const Dec128Args &a, int fr, unsigned char *ldsraw)
+{
+    uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
+    unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES); // all 256 constants: 8 dwords each
+    Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + FFT_TAB_BYTES + 256 * 32);
+    unsigned *xall = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES + 256 * 32 + DEC128_PLAN_BYTES);
+    const int tid = threadIdx.x;
+    {
+        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables);
+        for (int i = tid; i < 2 * FFT_NTAB; i += GF_NT) lt[i] = src[i];
+        for (int i = tid; i < 256 * 2; i += GF_NT) reinterpret_cast<uint4_t *>(tab)[i] = reinterpret_cast<const uint4_t *>(a.tab)[i];
+        for (int i = tid; i < DEC128_PLAN_BYTES / 16; i += GF_NT)
+            reinterpret_cast<uint4_t *>(pl)[i] = reinterpret_cast<const uint4_t *>(a.plan + (size_t)fr * DEC128_PLAN_BYTES)[i];
+    }
+    __syncthreads();
+
+    const unsigned la = lds_addr(ldsraw);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ch = wv & 1, hf = wv >> 1;
+    unsigned *const xch0 = xall + ch * FFT_XCH_DWORDS;
+    const int N = __builtin_amdgcn_readfirstlane(pl->n), m1 = __builtin_amdgcn_readfirstlane(pl->m1);
+    // descriptors: the frame as it was received (payload of the block at position 0 = byte 4), the payload area (block 1's samples
+    // = byte 0).  Offsets with bit 31 set lie beyond their range: such loads return zero, such stores are dropped -- that is how
+    // the erased originals read as zero and how lane 63 of the second column half (no column) stores nothing, without a branch.
+    const __amdgpu_buffer_rsrc_t rrx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.rx) + (size_t)fr * a.rx_frame_bytes + 4, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpay = __builtin_amdgcn_make_buffer_rsrc(a.payload_out + (size_t)fr * a.payload_frame_bytes, 0, 0x7fffffff, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned d[64];
+    {
+        const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
+        const bool live = col < 127u;
+        const unsigned lc4 = 4u * (live ? col : 126u);
+        const unsigned st4 = live ? lc4 : OOB;
+        const int b0 = 64 * hf;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int pos = __builtin_amdgcn_readfirstlane((int)pl->inv[b0 + i]); // position of original b0 + i in the received array, -1 = erased
+            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rrx, lc4, (pos < 0 ? 0 : pos) * 512, 0); // (erased: some block that exists)
+            d[i] = pos < 0 ? 0u : v;
+        }
+        // the received originals go to their places (getSlotData's layout: blocks 1..127 back to back, block 0 apart)
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int j = b0 + i; // (uniform)
+            const int pos = __builtin_amdgcn_readfirstlane((int)pl->inv[j]);
+            if (pos < 0) continue; // (uniform; nothing is defined in here: no join of register values)
+            if (i == 0 && hf == 0) {
+                if (a.block0_out && live) reinterpret_cast<unsigned *>(a.block0_out + (size_t)fr * 508)[col] = d[0];
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(d[i], rpay, st4, (j - 1) * 508, 0);
+            }
+        }
+        if (N == 0) return; // (copy only; workgroup-uniform, in front of the barriers)
+        unsigned par = 0u;
+#pragma unroll
+        for (int i = 0; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
+        (xch0 + lane)[(32 + hf) * 64] = par;
+    }
+
+    unsigned *const syn = xch0; // [i][lane]
+    if (m1) {
+        // cm256's DecodeM1: one recovery block, the erased original is the XOR of everything received
+        __syncthreads();
+        if (hf == 0) {
+            const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
+            const unsigned P = (xch0 + lane)[32 * 64] ^ (xch0 + lane)[33 * 64];
+            const int rp = __builtin_amdgcn_readfirstlane((int)pl->rpos[0]);
+            const unsigned rec = __builtin_amdgcn_raw_buffer_load_b32(rrx, col < 127u ? 4u * col : OOB, rp * 512, 0);
+            (syn + lane)[0] = col < 127u ? (P ^ rec) : 0u;
+        }
+        __syncthreads();
+    } else {
+        unsigned e[16];
+        fft_rows16(d, e, hf, la, xch0);
+        // syndromes of the received recovery rows among rows 16 hf .. 16 hf + 15: recovery ^ (P ^ (r c / q) * value_r)
+        const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
+        const unsigned ld4 = col < 127u ? 4u * col : OOB;
+        const unsigned P = (xch0 + lane)[32 * 64] ^ (xch0 + lane)[33 * 64];
+        unsigned rec[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ri = __builtin_amdgcn_readfirstlane((int)pl->rowidx[16 * hf + i]); // 255 = not received
+            const int rp = __builtin_amdgcn_readfirstlane((int)pl->rpos[ri & 31]);
+            rec[i] = __builtin_amdgcn_raw_buffer_load_b32(rrx, ld4, rp * 512, 0); // (a row that did not arrive: some block, not used)
+        }
+        __syncthreads(); // (both waves are through with the exchange rows: the syndromes take their place)
+        {
+            FftTabs R;
+            const unsigned lk = la + (unsigned)hf * 512u;
+            fft_issue<0, 160>(R, lk);
+            fft_for<16>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value, PP = i & 1;
+                fft_wait<PP>(R);
+                if constexpr (i + 1 < 16) fft_issue<PP ^ 1, 160 + i + 1>(R, lk);
+                const int ri = __builtin_amdgcn_readfirstlane((int)pl->rowidx[16 * hf + i]);
+                if (ri != 255) {
+                    unsigned v = rec[i] ^ P;
+                    fft_muladd<PP>(v, e[i], R);
+                    (syn + lane)[(ri & 31) * 64] = col < 127u ? v : 0u;
+                }
+            });
+        }
+        __syncthreads();
+    }
+
+    // erased originals = Minv x syndromes: this wave takes rows t = w + 4 u of its column half for w = hf and w = hf + 2 (up to 8 each);
+    // a syndrome dword is split into its selector words once and multiplied by the constants of all the wave's rows.  Two
+    // syndromes at a time, the next two (and the wave's constants for them: two 8-byte reads per syndrome) already on their way.
+    const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
+    unsigned acc[2][DEC128_MAXN / 4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int u = 0; u < DEC128_MAXN / 4; ++u) acc[g][u] = 0u;
+    const int nm0 = (N - hf + 3) >> 2, nm1 = (N - (hf + 2) + 3) >> 2; // rows w + 4 u < N
+    unsigned sy[2];
+    uint2_t mc[2][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        sy[k] = (syn + lane)[k * 64];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) mc[k][g] = *reinterpret_cast<const uint2_t *>(&pl->minv[k * DEC128_MAXN + (hf + 2 * g) * 8]);
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < N; i0 += 2) {
+        unsigned sy_next[2];
+        uint2_t mc_next[2][2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = (i0 + 2 + k) & (DEC128_MAXN - 1); // (past the end: rows that exist and are not used)
+            sy_next[k] = (syn + lane)[i * 64];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) mc_next[k][g] = *reinterpret_cast<const uint2_t *>(&pl->minv[i * DEC128_MAXN + (hf + 2 * g) * 8]);
+        }
+        const bool two = i0 + 1 < N; // (uniform)
+        const Sel sl0 = make_sel(sy[0]), sl1 = make_sel(two ? sy[1] : 0u);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int u = 0; u < DEC128_MAXN / 4; ++u) {
+                if (u < (g ? nm1 : nm0)) {
+                    const unsigned c0 = ((u < 4 ? mc[0][g].x : mc[0][g].y) >> (8 * (u & 3))) & 0xffu;
+                    const unsigned c1 = ((u < 4 ? mc[1][g].x : mc[1][g].y) >> (8 * (u & 3))) & 0xffu;
+                    // (a second syndrome that does not exist has the selector words of zero: its product is zero whatever the constant)
+                    acc[g][u] = __builtin_amdgcn_bitop3_b32(acc[g][u], mulc(sl0, *reinterpret_cast<const uint4_t *>(&tab[c0 * 8]), tab[c0 * 8 + 4]),
+                                                            mulc(sl1, *reinterpret_cast<const uint4_t *>(&tab[c1 * 8]), tab[c1 * 8 + 4]), 0x96);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            sy[k] = sy_next[k];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) mc[k][g] = mc_next[k][g];
+        }
+    }
+    const unsigned st4 = col < 127u ? 4u * col : OOB;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int u = 0; u < DEC128_MAXN / 4; ++u) {
+            if (u < (g ? nm1 : nm0)) {
+                const int yy = __builtin_amdgcn_readfirstlane((int)pl->ydst[hf + 2 * g + 4 * u]), y = yy & 0x7f;
+                const unsigned val = (yy & 0x80) ? 0u : acc[g][u]; // (strict mode: a block the reference's copy-back would miss stays a hole)
+                if (y >= 1) __builtin_amdgcn_raw_buffer_store_b32(val, rpay, st4, (y - 1) * 508, 0);
+                else if (a.block0_out && col < 127u) reinterpret_cast<unsigned *>(a.block0_out + (size_t)fr * 508)[col] = val;
+            }
+        }
+    }
+}

@@ -157,6 +157,48 @@ __device__ __forceinline__ void fft_fill_tables(const Enc128Args &a, unsigned ch
     __syncthreads();
 }
 
+// from a wave's 64 values (blocks 64 hf .. 64 hf + 63 of its 64 columns) to rows 16 hf .. 16 hf + 15 of the size-32 transform on
+// 128 + V5: inverse transform + t5 fold in registers, the hf = 0 wave's 32 coefficients go to the hf = 1 wave through the column
+// half's exchange area xch0 ([32][64] dwords; barrier), that one applies t6 and the first stage of the size-32 transform and hands
+// rows 0..15 back (barrier), then each wave finishes its size-16 transform.  Two __syncthreads inside: all four waves call it.
+__device__ __forceinline__ void fft_rows16(unsigned (&d)[64], unsigned (&e)[16], int hf, unsigned la, unsigned *xch0)
+{
+    FFT_STAMP(2);
+    fft_inverse64_fold(d, hf, la + (unsigned)(hf * 63 * 32), la);
+    FFT_STAMP(3);
+    unsigned *const xch = xch0 + fft_lane();
+    if (hf == 0) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) xch[i * 64] = d[i];
+    }
+    __syncthreads();
+    if (hf != 0) {
+        // t6 and the one block of stage 4, rows i and 16 + i together: the pair is finished (row i parked for the other wave, row
+        // 16 + i kept) before the next one is read -- 64 + 16 live values instead of 96
+        FftTabs R;
+        fft_issue<0, 127>(R, la);           // t6
+        fft_issue<1, 128 + 32 - 2>(R, la);  // stage 4
+        fft_wait<0>(R);
+        fft_wait<1>(R);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            unsigned va = xch[i * 64], vb = xch[(16 + i) * 64];
+            d[i] ^= va; fft_muladd<0>(va, d[i], R);
+            d[16 + i] ^= vb; fft_muladd<0>(vb, d[16 + i], R);
+            fft_muladd<1>(va, vb, R);
+            e[i] = vb ^ va;
+            xch[i * 64] = va;
+        }
+    }
+    __syncthreads();
+    if (hf == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e[i] = xch[i * 64];
+    }
+    FFT_STAMP(4);
+    fft_forward16(e, hf, la);
+}
+
 // one WORKGROUP of the encoder: frame list entry `fi`, a.rows <= FFT_MAX_ROWS.  Input handling (frame list, meta block derived in
 // place, fused framing copy) is gf_encode128_wg's, block for block.
 __device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi, unsigned char *ldsraw)
@@ -258,42 +300,8 @@ __device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi,
         for (int i = 0; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
         (xch0 + lane)[(32 + hf) * 64] = par; // (both halves' parities wait in LDS: one long-lived register less)
     }
-    FFT_STAMP(2);
-    fft_inverse64_fold(d, hf, la + (unsigned)(hf * 63 * 32), la);
-    FFT_STAMP(3);
-
     unsigned e[16];
-    unsigned *const xch = xch0 + fft_lane();
-    if (hf == 0) {
-#pragma unroll
-        for (int i = 0; i < 32; ++i) xch[i * 64] = d[i];
-    }
-    __syncthreads();
-    if (hf != 0) {
-        // t6 and the one block of stage 4, rows i and 16 + i together: the pair is finished (row i parked for the other wave, row
-        // 16 + i kept) before the next one is read -- 64 + 16 live values instead of 96
-        FftTabs R;
-        fft_issue<0, 127>(R, la);           // t6
-        fft_issue<1, 128 + 32 - 2>(R, la);  // stage 4
-        fft_wait<0>(R);
-        fft_wait<1>(R);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            unsigned la = xch[i * 64], lb = xch[(16 + i) * 64];
-            d[i] ^= la; fft_muladd<0>(la, d[i], R);
-            d[16 + i] ^= lb; fft_muladd<0>(lb, d[16 + i], R);
-            fft_muladd<1>(la, lb, R);
-            e[i] = lb ^ la;
-            xch[i * 64] = la;
-        }
-    }
-    __syncthreads();
-    if (hf == 0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) e[i] = xch[i * 64];
-    }
-    FFT_STAMP(4);
-    fft_forward16(e, hf, la);
+    fft_rows16(d, e, hf, la, xch0);
     // rows 16 hf + i
     {
         FftTabs R;

@@ -525,6 +525,7 @@ struct Dec128Args {
     const uint8_t *plan;        // [nframes] Dec128Plan
     const uint8_t *tab;         // 256 x 32 B multiplier tables
     const uint8_t *leaf_tables; // Karatsuba leaves of the encoder
+    const uint8_t *fft_tables;  // constants of the additive-FFT encoder (gf_decode128_fft_kernel)
     uint8_t *payload_out;       // [nframes][127 x 508]
     size_t payload_frame_bytes;
     uint8_t *block0_out;        // optional [nframes][508]
@@ -535,9 +536,13 @@ constexpr int DEC128_LDS_BYTES = 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4 + DEC
 #ifndef DEC128_WPE
 #define DEC128_WPE 4
 #endif
-__global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128Args a)
+// (OWN: the stand-alone kernel's form -- the LDS block is the function's own and the unit is the workgroup's index, as they were
+// while this was the kernel itself; handed a pointer and an index the same code needs six more registers than it has)
+template <bool OWN> __device__ __forceinline__ void gf_decode128_wg(const Dec128Args &a, int bx_in, unsigned char *lds_in)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char ldsraw[DEC128_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_own[OWN ? DEC128_LDS_BYTES : 16];
+    unsigned char *ldsraw = OWN ? lds_own : lds_in;
+    const int bx = OWN ? (int)blockIdx.x : bx_in;
     uint4_t *lt16 = reinterpret_cast<uint4_t *>(ldsraw);
     unsigned *lt4 = reinterpret_cast<unsigned *>(ldsraw + 8 * KLEAVES * 16);
     unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + 8 * KLEAVES * 20);                       // all 256 constants: 8 dwords each
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
     unsigned (*syn)[64] = reinterpret_cast<unsigned (*)[64]>(ldsraw + 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4);
     Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4 + DEC128_MAXN * 64 * 4);
     const int tid = threadIdx.x;
-    const int fr = blockIdx.x >> 1;
+    const int fr = bx >> 1;
     // (tables and plan records are 32- / 16-byte aligned: whole 16-byte loads, all of them in flight before the first LDS store)
     for (int i = tid; i < 8 * KLEAVES; i += GF_NT) {
         const uint4_t *src = reinterpret_cast<const uint4_t *>(a.leaf_tables) + (size_t)i * 2;
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
     __syncthreads();
 
     const int w = tid >> 6, lane = tid & 63;
-    const int col = (blockIdx.x & 1) * 64 + lane;
+    const int col = (bx & 1) * 64 + lane;
     const bool live = col < 127;
     const unsigned *rx = reinterpret_cast<const unsigned *>(a.rx + (size_t)fr * a.rx_frame_bytes) + 1 + (live ? col : 0);
     unsigned *pay = reinterpret_cast<unsigned *>(a.payload_out + (size_t)fr * a.payload_frame_bytes) + (live ? col : 0);
@@ -712,6 +717,32 @@ __global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128A
     }
 }
 
+
+__global__ __launch_bounds__(GF_NT, DEC128_WPE) void gf_decode128_kernel(Dec128Args a)
+{
+    gf_decode128_wg<true>(a, 0, nullptr);
+}
+
+// ... with the additive-FFT walk: a workgroup per frame; a frame that holds a recovery row beyond 31 takes the Karatsuba walk, its
+// two units one after the other
+#include "gf_decode128_fft.h"
+__global__ __launch_bounds__(GF_NT, 4) void gf_decode128_fft_kernel(Dec128Args a)
+{
+    constexpr int LDSB = DEC128_FFT_LDS_BYTES > DEC128_LDS_BYTES ? DEC128_FFT_LDS_BYTES : DEC128_LDS_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char ldsraw[LDSB];
+    const int fr = (int)blockIdx.x;
+    const Dec128Plan *gp = reinterpret_cast<const Dec128Plan *>(a.plan + (size_t)fr * DEC128_PLAN_BYTES);
+    if (gp->n > 0 && !gp->m1 && gp->maxrow >= FFT_MAX_ROWS) { // (workgroup-uniform)
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) {
+            gf_decode128_wg<false>(a, 2 * fr + u, ldsraw);
+            __syncthreads();
+        }
+        return;
+    }
+    gf_decode128_fft_wg(a, fr, ldsraw);
+}
+
 } // namespace
 
 hipError_t launch_gf_apply(const GfArgs &a, hipStream_t stream)
@@ -799,9 +830,10 @@ hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *
         // syndrome decoder: copies the received originals of EVERY frame and restores up to 32 erased ones; frames that need
         // more (nrec > 0 below) go on to the dense kernel
         Dec128Args k;
-        k.rx = rx; k.rx_frame_bytes = rx_frame_bytes; k.plan = d.plan2; k.tab = tab; k.leaf_tables = d.leaf_tables;
+        k.rx = rx; k.rx_frame_bytes = rx_frame_bytes; k.plan = d.plan2; k.tab = tab; k.leaf_tables = d.leaf_tables; k.fft_tables = d.fft_tables;
         k.payload_out = payload_out; k.payload_frame_bytes = payload_frame_bytes; k.block0_out = block0_out; k.nframes = nframes;
-        hipLaunchKernelGGL(gf_decode128_kernel, dim3(2 * nframes), dim3(GF_NT), 0, stream, k);
+        if (d.use_fft && d.fft_tables) hipLaunchKernelGGL(gf_decode128_fft_kernel, dim3(nframes), dim3(GF_NT), 0, stream, k);
+        else hipLaunchKernelGGL(gf_decode128_kernel, dim3(2 * nframes), dim3(GF_NT), 0, stream, k);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (max_rows <= DEC128_MAXN) return hipSuccess; // (no frame can need the dense kernel)

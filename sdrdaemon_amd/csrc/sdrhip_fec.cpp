@@ -100,6 +100,7 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
     // syndrome decoder (default) or the dense matrix kernel alone (ctx option dec_path = dense: A / B and fallback)
     d.plan2 = c->opt.dec_syndrome ? base : nullptr;
     d.leaf_tables = c->enc_leaves;
+    d.fft_tables = c->enc_fft; d.use_fft = c->opt.enc_fft;
     const uint8_t *idx_dev = nullptr;
     if (indices) {
         const size_t nb = nframes * (size_t)SDRHIP_NB_ORIGINAL;

@@ -290,6 +290,8 @@ struct DecodeBuffers {
     int32_t *nrec;            // [nframes][2]
     uint8_t *plan2;           // [nframes][DECODE_PLAN2_BYTES] records of the syndrome decoder, NULL = dense path only
     const uint8_t *leaf_tables; // Karatsuba leaf tables of the 128-original encoder (the syndrome decoder walks the same tree)
+    const uint8_t *fft_tables;  // constants of the additive-FFT encoder (gf_decode128_fft.h); NULL or use_fft = 0: the Karatsuba walk
+    int use_fft;
     static size_t bytes(size_t nframes) { return nframes * (128 * 128 + 4 * 128 * sizeof(int16_t) + 2 * sizeof(int32_t) + DECODE_PLAN2_BYTES) + 64; }
 };
 // plan + scatter + apply, all on the stream, no host synchronisation; max_rows = upper bound of the recovery blocks a
