@@ -32,7 +32,7 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
 {
     if (nframes == 0 || nb_fec <= 0) return SDRHIP_OK;
     hipError_t e;
-    if (nb_fec >= ENC128_MIN_ROWS && rec_frame_bytes % 4 == 0 && frame_bytes % 4 == 0) {
+    if (nb_fec >= enc128_min_rows(c) && rec_frame_bytes % 4 == 0 && frame_bytes % 4 == 0) {
         // structured encoder (Karatsuba over the XOR-convolution form of the Cauchy rows); frame lists of
         // the generic kernel come in groups of GF_FRAMES_PER_GROUP, this kernel takes them flat
         Enc128Args k;

@@ -90,7 +90,11 @@ struct EncodeLin {
     size_t stride;
     int cap, first, pending;
 };
-inline bool fec_encode_fuses_framing(int nb_fec) { return nb_fec >= sdrhip::ENC128_MIN_ROWS; }
+// smallest number of recovery blocks the structured encoder serves: 13 for the Karatsuba walk (ENC128_MIN_ROWS: below, the generic
+// matrix kernel's rows x 128 products are fewer than one 32-row tile's), enc_min_rows (default 1) for the additive FFT, whose 592
+// products do not depend on the row count (profiles/r05_enc_rows.txt)
+int enc128_min_rows(const sdrhip_ctx *c);
+inline bool fec_encode_fuses_framing(const sdrhip_ctx *c, int nb_fec) { return nb_fec >= enc128_min_rows(c); }
 int fec_encode_device(sdrhip_ctx *ctx, const uint8_t *frames, size_t frame_bytes, size_t nframes, int nb_fec, uint8_t *rec,
                       size_t rec_frame_bytes, const int32_t *frame_list_dev = nullptr, int ngroups = 0, const EncodeLin *lin = nullptr);
 // the structured 128-original encoder on prepared arguments (the Rx pipe's deferred encode)
@@ -126,6 +130,7 @@ struct CtxOptions {
     int rx_direct = 1;
     int tx_overlap = 1;                    // pipelined Tx pipe: 1 = decode of this batch on the second stream beside the interpolator of the previous one, 0 = one stream
     int enc_fft = 1;                       // structured 128-original encoder, rows <= 32: additive FFT (1) or the Karatsuba XOR-convolution walk (0)
+    int enc_min_rows = 1;                  // ... the FFT from this many recovery blocks on (the generic matrix kernel below)
     int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)
     int dec_strict = 0;                    // batched decode delivers only what the reference's copy-back loop delivers (SDRdaemonFECBuffer.cpp:204-211)
     int dec_max_rows = 128;                // upper bound of the recovery blocks a received frame can have used (the sender's fecblk)

@@ -483,7 +483,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     bool use_lin = false, pack_with_encoder = false;
     FrameArgs fa;
     memset(&fa, 0, sizeof(fa));
-    const bool structured = R >= ENC128_MIN_ROWS && frame_bytes % 4 == 0; // gf_encode128_kernel serves this setting
+    const bool structured = R >= enc128_min_rows(c) && frame_bytes % 4 == 0; // gf_encode128_kernel serves this setting
     const bool filterless = L == 0 || (rx->cfg.fcpos != SDRHIP_FC_CEN && L <= 2); // Decimators.cpp:22-91,127-170: no cascade kernel
     const Enc128Args *fuse = rx->late.encode && (c->opt.rx_fused == 1 || c->opt.rx_fused == 2) ? &rx->late.k : nullptr;
     // overlap mode: the waiting encode will run on the second stream BESIDE this call's decimator (rx_settle below), which therefore
@@ -504,7 +504,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         if (fused) rx->late.encode = false;
         // the frames that lie entirely inside this call's samples are laid out by the encoder (fused copy); K2 does
         // the frame that was open when the call began, the one left open at its end, meta blocks and headers
-        if (fec_encode_fuses_framing(R)) {
+        if (fec_encode_fuses_framing(c, R)) {
             const size_t first = rx->pending_samples ? 1 : 0;
             if (done > first && frame_bytes % 4 == 0) {
                 elin.lin = lin.as<unsigned>(); elin.stride = lstride; elin.cap = (int)rx->cap_frames;
