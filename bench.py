@@ -351,7 +351,7 @@ def extra_configs(ctx, dev, x, kind, ids):
     # context's second stream BESIDE that decimator (LDS-DMA ring of depth 3 so that two encoder workgroups fit on every CU).
     # Steady state: every timed step holds one decimation and one encode.
     for fused, label, kern in ((1, "CM256 encoder workgroups inside the decimator's launch (rx_fused_kernel)", "rx_fused_kernel<4,true>"),
-                               (3, "CM256 encoder on the second stream beside the decimator (two streams, ring depth 3)", "decim_mfma_kernel<4,true> (ring 3) || gf_encode128_kernel")):
+                               (3, "CM256 encoder on the second stream beside the decimator (two streams, ring depth 3)", "decim_mfma_kernel<4,true> (ring 3) || gf_encode128_fft_kernel")):
         ctx.set_option("rx_fused", fused)
         try:
             rxp = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
@@ -418,7 +418,7 @@ def extra_configs(ctx, dev, x, kind, ids):
     out.append({"config": "configs[3], pipelined plumbing: %d streams x %d frames per step, decode of this batch on the second stream beside the "
                           "interpolator of the previous batch, samples delivered one call late" % (Stx, F),
                 "ms_per_step": round(wall, 4), "value": round(nout / wall / 1e3, 1), "unit": "Msamples/s (output)",
-                "roofline": roof((4.0 + 128.0 * 512.0 / 258064.0) * nout, wall, interp_kernel_name(ctx) + " || gf_decode128_kernel (config-4 algorithmic "
+                "roofline": roof((4.0 + 128.0 * 512.0 / 258064.0) * nout, wall, interp_kernel_name(ctx) + " || gf_decode128_fft_kernel (config-4 algorithmic "
                                  "bytes, 4.254 B per output; the launches overlap, the step's wall time is the launch time)"),
                 "verified": txp_verified})
     return out
@@ -816,6 +816,9 @@ def main():
                          "kernel": kname, "launches": dec_n, "timer_stride": args.timer_stride, "avg_launch_ms": round(avg_ms, 4), "plan": plan,
                          "algorithmic_bytes_per_launch": BYTES_DECIM * per_launch_samples,
                          "pipe_gbps_config3": round(BYTES_CONFIG3 * value * 1e6 / 1e9 / world, 1),
+                         # the PATH the metric names (decimate + framing + FEC encode, config-3 algorithmic bytes) against the same peak
+                         "path_frac": round(BYTES_CONFIG3 * value * 1e6 / 1e9 / world / HBM_PEAK_GBS, 4),
+                         "arrangement": "rx_direct: matrix-core decimator stores in the frame layout; CM256 encoder = additive FFT (gf_encode128_fft_kernel); 2 launches per step",
                          "fec_encode_avg_launch_ms": round(fec_ms / max(fec_n, 1), 4), "fec_encode_launches": fec_n},
         }
         res["verified"] = verified

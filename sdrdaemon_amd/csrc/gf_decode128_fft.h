@@ -16,12 +16,13 @@
 constexpr int DEC128_FFT_LDS_BYTES = FFT_TAB_BYTES + 256 * 32 + DEC128_PLAN_BYTES + 2 * FFT_XCH_DWORDS * 4;
 static_assert(DEC128_PLAN_BYTES % 16 == 0 && DEC128_MAXN == 32, "plan record layout");
 
+template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch);
+
 __device__ __forceinline__ void gf_decode128_fft_wg(const Dec128Args &a, int fr, unsigned char *ldsraw)
 {
     uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
     unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES); // all 256 constants: 8 dwords each
     Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + FFT_TAB_BYTES + 256 * 32);
-    unsigned *xall = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES + 256 * 32 + DEC128_PLAN_BYTES);
     const int tid = threadIdx.x;
     {
         const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables);
@@ -31,10 +32,19 @@ __device__ __forceinline__ void gf_decode128_fft_wg(const Dec128Args &a, int fr,
             reinterpret_cast<uint4_t *>(pl)[i] = reinterpret_cast<const uint4_t *>(a.plan + (size_t)fr * DEC128_PLAN_BYTES)[i];
     }
     __syncthreads();
-
-    const unsigned la = lds_addr(ldsraw);
+    // (the block half is a template parameter of everything behind this point, like the encoder's: gf_encode128_fft_wave)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ch = wv & 1, hf = wv >> 1;
+    if (wv >> 1) gf_decode128_fft_wave<1>(a, fr, ldsraw, wv & 1);
+    else gf_decode128_fft_wave<0>(a, fr, ldsraw, wv & 1);
+}
+
+template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch)
+{
+    constexpr int hf = HF;
+    unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES); // all 256 constants: 8 dwords each
+    Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + FFT_TAB_BYTES + 256 * 32);
+    unsigned *xall = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES + 256 * 32 + DEC128_PLAN_BYTES);
+    const unsigned la = lds_addr(ldsraw);
     unsigned *const xch0 = xall + ch * FFT_XCH_DWORDS;
     const int N = __builtin_amdgcn_readfirstlane(pl->n), m1 = __builtin_amdgcn_readfirstlane(pl->m1);
     // descriptors: the frame as it was received (payload of the block at position 0 = byte 4), the payload area (block 1's samples
@@ -89,7 +99,7 @@ __device__ __forceinline__ void gf_decode128_fft_wg(const Dec128Args &a, int fr,
         __syncthreads();
     } else {
         unsigned e[16];
-        fft_rows16(d, e, hf, la, xch0);
+        fft_rows16<HF>(d, e, la, xch0);
         // syndromes of the received recovery rows among rows 16 hf .. 16 hf + 15: recovery ^ (P ^ (r c / q) * value_r)
         const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
         const unsigned ld4 = col < 127u ? 4u * col : OOB;

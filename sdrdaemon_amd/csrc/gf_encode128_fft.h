@@ -19,7 +19,8 @@
 //      16 + r, behind it the two halves of 16 are independent;
 //   4. recovery_r = P ^ (r c / q) * value_r.
 // 384 - 63 (the leading block of every stage of the first half has the constant 0: skipped) + 64 + 32 + 80 + 32 = 529 constant
-// multiplications and ~1200 XORs per column: ~45 % of the instructions of the Karatsuba walk.
+// multiplications and ~1200 XORs per column: ~45 % of the instructions of the Karatsuba walk (measured: 13.9 M against 25.6 M
+// VALU wave-instructions per 1040 frames).
 // (tools/experiments_r05/lch_encode_proto.py is the same algorithm in numpy, checked against the oracle's cm256_encode.)
 //
 // Mapping: a lane owns one 4-byte column of one frame; a WORKGROUP is one frame, its four waves = (column half ch, block half hf):
@@ -39,9 +40,6 @@ constexpr int ENC128_FFT_LDS_BYTES = FFT_TAB_BYTES + 2 * FFT_XCH_DWORDS * 4;
 constexpr int FFT_MAX_ROWS = 32;
 #ifndef FFT_WAVES_PER_EU
 #define FFT_WAVES_PER_EU 5 // 96 registers: five workgroups per CU hold all 1040 + K2's workgroups of the headline step at once
-#endif
-#ifndef FFT_SKIP_ZERO
-#define FFT_SKIP_ZERO 0
 #endif
 
 // The multiplier tables travel through two register sets: while block n is multiplied, the table of block n + 1 is on its way from
@@ -91,7 +89,7 @@ __host__ __device__ constexpr int fft_inv_stage(int n) { int k = 0; while (n >= 
 
 // inverse transform of size 64 (values on the coset 64 hf + V6 -> novel-basis coefficients) and the t5 fold: d[0..31] = the half's
 // 32 coefficients on 128 + V5.  lh: LDS address of table 0 of this half; la: of table 0.
-__device__ __forceinline__ void fft_inverse64_fold(unsigned (&d)[64], int hf, unsigned lh, unsigned la)
+template <int HF> __device__ __forceinline__ void fft_inverse64_fold(unsigned (&d)[64], unsigned lh, unsigned la)
 {
     FftTabs R;
     fft_issue<0, 0>(R, lh);
@@ -103,7 +101,7 @@ __device__ __forceinline__ void fft_inverse64_fold(unsigned (&d)[64], int hf, un
 #pragma unroll
         for (int i = 0; i < h; ++i) d[blk + h + i] ^= d[blk + i];
         // (the leading block of a stage sits on the coset representative 64 hf: s^_k(0) = 0, nothing to multiply in the first half)
-        if (!FFT_SKIP_ZERO || j != 0 || hf != 0) {
+        if constexpr (j != 0 || HF != 0) {
 #pragma unroll
             for (int i = 0; i < h; ++i) fft_muladd<P>(d[blk + i], d[blk + h + i], R);
         }
@@ -161,18 +159,22 @@ __device__ __forceinline__ void fft_fill_tables(const Enc128Args &a, unsigned ch
 // 128 + V5: inverse transform + t5 fold in registers, the hf = 0 wave's 32 coefficients go to the hf = 1 wave through the column
 // half's exchange area xch0 ([32][64] dwords; barrier), that one applies t6 and the first stage of the size-32 transform and hands
 // rows 0..15 back (barrier), then each wave finishes its size-16 transform.  Two __syncthreads inside: all four waves call it.
-__device__ __forceinline__ void fft_rows16(unsigned (&d)[64], unsigned (&e)[16], int hf, unsigned la, unsigned *xch0)
+// HF is a template parameter: the two block halves run different code (the first half's stages begin with a block whose constant
+// is zero -- 63 of its 224 multiplications -- and the exchange is not symmetric); as a run-time value the skipped blocks became
+// branches inside the network and the register allocator spilled at every join.
+template <int HF> __device__ __forceinline__ void fft_rows16(unsigned (&d)[64], unsigned (&e)[16], unsigned la, unsigned *xch0)
 {
+    constexpr int hf = HF;
     FFT_STAMP(2);
-    fft_inverse64_fold(d, hf, la + (unsigned)(hf * 63 * 32), la);
+    fft_inverse64_fold<HF>(d, la + (unsigned)(hf * 63 * 32), la);
     FFT_STAMP(3);
     unsigned *const xch = xch0 + fft_lane();
-    if (hf == 0) {
+    if constexpr (hf == 0) {
 #pragma unroll
         for (int i = 0; i < 32; ++i) xch[i * 64] = d[i];
     }
     __syncthreads();
-    if (hf != 0) {
+    if constexpr (hf != 0) {
         // t6 and the one block of stage 4, rows i and 16 + i together: the pair is finished (row i parked for the other wave, row
         // 16 + i kept) before the next one is read -- 64 + 16 live values instead of 96
         FftTabs R;
@@ -191,7 +193,7 @@ __device__ __forceinline__ void fft_rows16(unsigned (&d)[64], unsigned (&e)[16],
         }
     }
     __syncthreads();
-    if (hf == 0) {
+    if constexpr (hf == 0) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) e[i] = xch[i * 64];
     }
@@ -201,14 +203,12 @@ __device__ __forceinline__ void fft_rows16(unsigned (&d)[64], unsigned (&e)[16],
 
 // one WORKGROUP of the encoder: frame list entry `fi`, a.rows <= FFT_MAX_ROWS.  Input handling (frame list, meta block derived in
 // place, fused framing copy) is gf_encode128_wg's, block for block.
-__device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi, unsigned char *ldsraw)
+// (HF = the wave's block half as a template parameter: the two halves run different code, see fft_rows16; the dispatch sits at the
+// very top -- gf_encode128_fft_wg -- so that no register value has to survive a join of the two variants)
+template <int HF> __device__ __forceinline__ void gf_encode128_fft_wave(const Enc128Args &a, int fi, unsigned char *ldsraw, int ch)
 {
-    FFT_STAMP(0);
-    fft_fill_tables(a, ldsraw);
-    FFT_STAMP(1);
+    constexpr int hf = HF;
     const unsigned la = lds_addr(ldsraw);
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ch = wv & 1, hf = wv >> 1;
     const int lane = (int)fft_lane();
     const int fr = a.gen_done > 0 ? (fi / a.gen_done) * a.gen_cap + fi % a.gen_done : (a.frame_list ? __builtin_amdgcn_readfirstlane(a.frame_list[fi]) : fi);
     if (fr < 0 || fr >= a.nframes) return; // (workgroup-uniform: all four waves leave in front of the barriers below)
@@ -301,7 +301,7 @@ __device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi,
         (xch0 + lane)[(32 + hf) * 64] = par; // (both halves' parities wait in LDS: one long-lived register less)
     }
     unsigned e[16];
-    fft_rows16(d, e, hf, la, xch0);
+    fft_rows16<HF>(d, e, la, xch0);
     // rows 16 hf + i
     {
         FftTabs R;
@@ -335,4 +335,13 @@ __device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi,
 #define FFT_LDS_PAD 0 // (experiment: extra bytes of LDS per workgroup = fewer workgroups per CU)
 #endif
 constexpr int ENC128_FFT_KERNEL_LDS = ENC128_FFT_LDS_BYTES + FFT_LDS_PAD;
+__device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi, unsigned char *ldsraw)
+{
+    FFT_STAMP(0);
+    fft_fill_tables(a, ldsraw);
+    FFT_STAMP(1);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wv >> 1) gf_encode128_fft_wave<1>(a, fi, ldsraw, wv & 1);
+    else gf_encode128_fft_wave<0>(a, fi, ldsraw, wv & 1);
+}
 __device__ __forceinline__ void gf_encode128_fft_unit(const Enc128Args &a, int fi, unsigned char *ldsraw) { gf_encode128_fft_wg(a, fi, ldsraw); }
