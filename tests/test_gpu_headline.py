@@ -151,6 +151,38 @@ def test_headline_rx_arrangements(ctx, direct, enc):
         ctx.set_option("enc_path", "fft")
 
 
+@pytest.mark.parametrize("log2,S,n,R", [(2, 3, 1 << 21, 8), (3, 2, 1 << 22, 1), (5, 8, 1 << 22, 32), (6, 4, 1 << 23, 16)])
+def test_rx_direct_framing_every_matrix_core_cascade(ctx, log2, S, n, R):
+    """the matrix-core decimator's frame-layout stores for decimate4 .. 64_cen (decimate16: the headline digests): three ragged calls
+    -- the second and third begin inside an open frame, blocks and frames end inside a lane pair's two samples -- against the
+    stream-order arrangement (K2 + fused copy), which the reference chain tests pin; both must have run the matrix-core kernel"""
+    import torch
+
+    import sdrdaemon_amd as sd
+    import signals
+
+    x = torch.stack([signals.hash_noise_torch(n, 7000 + 13 * log2 + s, "cuda") for s in range(S)])
+    cuts = [0, (n // 3) & ~((1 << log2) * 4 - 1), (2 * n // 3 + 4096) & ~((1 << log2) * 4 - 1), n]
+    ctx.set_option("decim_path", "mfma")
+    try:
+        outs = []
+        for direct in (0, 1):
+            ctx.set_option("rx_direct", direct)
+            rx = sd.RxPipe(ctx, S, log2decim=log2, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=R,
+                           center_frequency_khz=435000, sample_rate=48000)
+            fr = []
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                fr.append(rx.process_view(x[:, a:b], tv_sec=5, tv_usec=6).torch().clone())
+                assert rx.last_plan()["path"] == "mfma", (direct, rx.last_plan())
+            outs.append(fr)
+        ctx.synchronize()
+        for u, v in zip(*outs):
+            assert u.shape == v.shape and u.shape[1] > 0 and torch.equal(u, v)
+    finally:
+        ctx.set_option("rx_direct", 1)
+        ctx.set_option("decim_path", "auto")
+
+
 def test_headline_one_stream_2p27(ctx):
     """configs[2] literally: one stream of 2^27 samples through the decimator and through the Rx pipe, whole outputs"""
     import torch
