@@ -420,7 +420,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
             DevBuf bigger;
             // the window: TWO calls' frames (round 5; four until then).  The step rewrites what it wrote two calls ago: 2 x 84 MB per
             // 8-stream bank stay in the 256 MB of Infinity Cache, and on this memory system a write stream that stays there
-            // costs the read stream beside it less (profiles/r05_rx_window.txt: decimator launch 0.2435 -> 0.2335 ms, encoder
+            // costs the read stream beside it less (profiles/r05_rx_direct.txt: decimator launch 0.2435 -> 0.2335 ms, encoder
             // launch 0.052 -> 0.049 ms; a window of one call wraps -- a copy of the open frames -- on every call).  SDRHIP_RX_WINDOW = A / B
             // (pipelined pipes keep the previous call's frames until they are delivered: four calls, as before)
             static const size_t wenv = getenv("SDRHIP_RX_WINDOW") ? (size_t)atoi(getenv("SDRHIP_RX_WINDOW")) : 0;

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round-4 evidence set (GPU box): bench line, kernel trace + PMC passes of the headline command and of the Tx pipe, kernel tables
+# evidence set of the round (R) (GPU box): bench line, kernel trace + PMC passes of the headline command and of the Tx pipe, kernel tables
 cd $GRAFT_REPO_ROOT
-R=r04
+R=r05
 python bench.py --cpu-seconds 12 > gpurun_out/${R}_bench.json 2> gpurun_out/${R}_bench.err
 BENCH_ARGS="--no-configs --no-verify" bash tools/prof.sh > /dev/null 2>&1
 cp gpurun_out/prof_bench/summary.txt gpurun_out/${R}_headline_rocprofv3_summary.txt
