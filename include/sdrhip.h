@@ -72,9 +72,14 @@ void sdrhip_ctx_destroy(sdrhip_ctx *ctx);
 int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
 /* Kernel-path knobs for tests and tools (production code never needs them).  The defaults are read from the environment
  * ONCE, when the context is created (SDRHIP_DECIM_PATH, SDRHIP_MFMA_SPAN, SDRHIP_MFMA_MIN, SDRHIP_INTERP_PATH,
- * SDRHIP_INTERP_SPAN, SDRHIP_RX_FUSED); keys: "decim_path" = auto | valu | mfma, "mfma_span" / "mfma_min" / "interp_span" =
- * decimal sample counts, "interp_path" = auto | wave | valu | mfma (wave = K5w, the default from interpolate4 up; valu = K5), "rx_fused" = 0 | 1, "dec_path" = syndrome | dense.  Every setting
- * computes the same bytes.  One knob is a promise, not a path: "dec_max_rows" = 1..128 (default 128), the most recovery
+ * SDRHIP_INTERP_SPAN, SDRHIP_RX_FUSED, SDRHIP_RX_DIRECT, SDRHIP_ENC_PATH, SDRHIP_ENC_MIN_ROWS, SDRHIP_MFMA_RING, SDRHIP_TX_OVERLAP); keys:
+ * "decim_path" = auto | valu | mfma, "mfma_span" / "mfma_min" / "interp_span" = decimal sample counts, "interp_path" = auto | wave | valu
+ * (wave = K5w, the default from interpolate4 up; valu = K5), "rx_fused" = 0 | 1 | 2 | overlap (pipelined Rx: where the deferred encode
+ * runs), "rx_direct" = 1 | 0 (Rx pipe on the matrix-core decimator: frame-layout stores, the default, or stream order + framing pass),
+ * "enc_path" = fft | karatsuba (CM256 128 + R encoder and the batched decoder's walk: additive FFT for R <= 32, the default, or the
+ * Karatsuba XOR-convolution walk), "enc_min_rows" = 1..32 (fewest recovery blocks the FFT encoder serves; below: the generic matrix
+ * kernel), "mfma_ring" = 4 | 3, "tx_overlap" = 1 | 0 (pipelined Tx: decode on the second stream), "dec_path" = syndrome | dense.  Every
+ * setting computes the same bytes.  One knob is a promise, not a path: "dec_max_rows" = 1..128 (default 128), the most recovery
  * blocks a received frame can carry (the sender's fecblk, known from the meta block); <= 32 spares the batched decoder the
  * launches of its fallback kernel.  The promise is checked on the device: a frame that carries MORE recovery blocks than
  * dec_max_rows is left as received (like an undecodable frame: missing originals read zero) and counted, see
