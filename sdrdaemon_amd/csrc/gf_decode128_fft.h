@@ -63,7 +63,7 @@ template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const De
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
             const int pos = __builtin_amdgcn_readfirstlane((int)pl->inv[b0 + i]); // position of original b0 + i in the received array, -1 = erased
-            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rrx, lc4, (pos < 0 ? 0 : pos) * 512, 0); // (erased: some block that exists)
+            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rrx, lc4, (pos < 0 ? 0 : pos & 127) * 512, 0); // (erased: some block that exists)
             d[i] = pos < 0 ? 0u : v;
         }
         // the received originals go to their places (getSlotData's layout: blocks 1..127 back to back, block 0 apart)
@@ -92,7 +92,7 @@ template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const De
         if (hf == 0) {
             const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
             const unsigned P = (xch0 + lane)[32 * 64] ^ (xch0 + lane)[33 * 64];
-            const int rp = __builtin_amdgcn_readfirstlane((int)pl->rpos[0]);
+            const int rp = __builtin_amdgcn_readfirstlane((int)pl->rpos[0]) & 127;
             const unsigned rec = __builtin_amdgcn_raw_buffer_load_b32(rrx, col < 127u ? 4u * col : OOB, rp * 512, 0);
             (syn + lane)[0] = col < 127u ? (P ^ rec) : 0u;
         }
@@ -108,8 +108,8 @@ template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const De
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ri = __builtin_amdgcn_readfirstlane((int)pl->rowidx[16 * hf + i]); // 255 = not received
-            const int rp = __builtin_amdgcn_readfirstlane((int)pl->rpos[ri & 31]);
-            rec[i] = __builtin_amdgcn_raw_buffer_load_b32(rrx, ld4, rp * 512, 0); // (a row that did not arrive: some block, not used)
+            const int rp = ri == 255 ? 0 : __builtin_amdgcn_readfirstlane((int)pl->rpos[ri & 31]) & 127; // (a row that did not arrive: block 0, not used)
+            rec[i] = __builtin_amdgcn_raw_buffer_load_b32(rrx, ld4, rp * 512, 0);
         }
         __syncthreads(); // (both waves are through with the exchange rows: the syndromes take their place)
         {

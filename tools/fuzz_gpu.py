@@ -47,6 +47,9 @@ while time.time() - t0 < budget and (max_it == 0 or it < max_it):
     it += 1
     rs = np.random.RandomState(seed0 * 100003 + it)
     what = rs.choice(["decim", "interp", "rx", "tx", "fec"], p=[0.3, 0.2, 0.2, 0.1, 0.2])
+    if os.environ.get("FUZZ_VERBOSE"):  # (a fault kills the process: the last line names the iteration)
+        ctx.synchronize()
+        print("it", it, what, flush=True)
     # decimator kernel selection per iteration: the VALU cascade, the matrix-core cascade (short spans so that small
     # inputs run many waves + the VALU head / tail pieces), or the library's own choice
     ctx.set_option("decim_path", str(rs.choice(["auto", "valu", "mfma", "mfma"])))
@@ -54,6 +57,8 @@ while time.time() - t0 < budget and (max_it == 0 or it < max_it):
     ctx.set_option("rx_fused", int(rs.choice([0, 1, 3])))  # pipelined Rx: the waiting encode in its own launch / inside the decimator's / on the second stream
     ctx.set_option("mfma_ring", int(rs.choice([3, 4])))      # LDS-DMA ring depth of the decimate16 matrix-core kernel
     ctx.set_option("tx_overlap", int(rs.randint(0, 2)))      # pipelined Tx: decode on the second stream / on the first
+    ctx.set_option("rx_direct", int(rs.randint(0, 2)))       # matrix-core decimator inside the Rx pipe: frame-layout stores / stream order + framing pass
+    ctx.set_option("enc_path", str(rs.choice(["fft", "fft", "karatsuba"])))  # CM256 128 + R encoder and the syndrome decoder's walk
     ctx.set_option("dec_path", str(rs.choice(["syndrome", "syndrome", "dense"])))
     ctx.set_option("interp_path", str(rs.choice(["wave", "wave", "valu"])))     # K5w (default) / K5
     ctx.set_option("interp_span", int(rs.choice([0, 0, 128, 256, 640, 2048])))  # segment length in inputs (0 = the planner's)
