@@ -39,7 +39,7 @@ constexpr int FFT_XCH_DWORDS = 32 * 64 + 2 * 64;
 constexpr int ENC128_FFT_LDS_BYTES = FFT_TAB_BYTES + 2 * FFT_XCH_DWORDS * 4;
 constexpr int FFT_MAX_ROWS = 32;
 #ifndef FFT_WAVES_PER_EU
-#define FFT_WAVES_PER_EU 5 // 96 registers: five workgroups per CU hold all 1040 + K2's workgroups of the headline step at once
+#define FFT_WAVES_PER_EU 4 // (5 = 96 registers measured the same until the tables ran two blocks ahead: the third set does not fit in 96)
 #endif
 
 // The multiplier tables travel through two register sets: while block n is multiplied, the table of block n + 1 is on its way from
@@ -48,8 +48,8 @@ constexpr int FFT_MAX_ROWS = 32;
 // wave waits ~100 cycles 190 times).  asm statements keep the loads in program order; the wait statement re-defines the registers
 // ("+v"), so nothing reads them between issue and wait.
 struct FftTabs {
-    uint4_t t[2];
-    unsigned c[2];
+    uint4_t t[3]; // (the third set: the size-64 inverse transform runs TWO blocks ahead -- its first stage has one butterfly per block)
+    unsigned c[3];
 };
 template <int P, int IDX> __device__ __forceinline__ void fft_issue(FftTabs &R, unsigned la)
 {
@@ -59,6 +59,11 @@ template <int P, int IDX> __device__ __forceinline__ void fft_issue(FftTabs &R, 
 template <int P> __device__ __forceinline__ void fft_wait(FftTabs &R)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R.t[P]), "+v"(R.c[P])::"memory");
+}
+// ... while the NEXT block's table (two LDS reads, issued behind this one's: LDS operations of a wave return in order) stays in flight
+template <int P> __device__ __forceinline__ void fft_wait_ahead(FftTabs &R)
+{
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(R.t[P]), "+v"(R.c[P])::"memory");
 }
 // a ^= T * b in four-input XOR form (v_bitop3 + v_xor)
 template <int P> __device__ __forceinline__ void fft_muladd(unsigned &a, unsigned &b, const FftTabs &R)
@@ -93,11 +98,12 @@ template <int HF> __device__ __forceinline__ void fft_inverse64_fold(unsigned (&
 {
     FftTabs R;
     fft_issue<0, 0>(R, lh);
+    fft_issue<1, 1>(R, lh);
     fft_for<63>([&](auto nc) __attribute__((always_inline)) {
-        constexpr int n = decltype(nc)::value, k = fft_inv_stage(n), h = 1 << k, j = n - (64 - (64 >> k)), blk = j * 2 * h, P = n & 1;
-        fft_wait<P>(R);
-        if constexpr (n + 1 < 63) fft_issue<P ^ 1, n + 1>(R, lh);
-        else fft_issue<P ^ 1, 126>(R, la); // t5
+        constexpr int n = decltype(nc)::value, k = fft_inv_stage(n), h = 1 << k, j = n - (64 - (64 >> k)), blk = j * 2 * h, P = n % 3;
+        fft_wait_ahead<P>(R); // (block n + 1's table -- t5 behind the last block -- is on its way)
+        if constexpr (n + 2 < 63) fft_issue<(n + 2) % 3, n + 2>(R, lh);
+        else if constexpr (n + 2 == 63) fft_issue<(n + 2) % 3, 126>(R, la); // t5
 #pragma unroll
         for (int i = 0; i < h; ++i) d[blk + h + i] ^= d[blk + i];
         // (the leading block of a stage sits on the coset representative 64 hf: s^_k(0) = 0, nothing to multiply in the first half)
@@ -106,9 +112,9 @@ template <int HF> __device__ __forceinline__ void fft_inverse64_fold(unsigned (&
             for (int i = 0; i < h; ++i) fft_muladd<P>(d[blk + i], d[blk + h + i], R);
         }
     });
-    fft_wait<1>(R);
+    fft_wait<63 % 3>(R);
 #pragma unroll
-    for (int i = 0; i < 32; ++i) fft_muladd<1>(d[i], d[32 + i], R);
+    for (int i = 0; i < 32; ++i) fft_muladd<63 % 3>(d[i], d[32 + i], R);
 }
 
 // rows 16 hh .. 16 hh + 15 of the size-32 transform on 128 + V5 behind its first stage: stages 3..0 on 16 values; the tables of
