@@ -262,7 +262,11 @@ size_t sdrhip_rx_max_frames(const sdrhip_rx *rx, size_t n_in);
  * slots the decimator's waves leave empty).  Same bytes, one call later.  sdrhip_rx_flush encodes and delivers the frames the
  * last call completed (end of stream, before switching the mode off, and before a sdrhip_rx_reconfigure that changes fecblk:
  * the waiting frames carry the old frame size; reconfigure refuses otherwise).  frames_out of a pipelined call must hold
- * sdrhip_rx_max_frames() frames per stream. */
+ * sdrhip_rx_max_frames() frames per stream.
+ * What it is for: the reference's delivery semantics, and an A / B partner.  It is NOT the fast path on an MI355X: both kernels run
+ * at the board's power cap, co-resident they take the sum of their times (DESIGN.md "Whole pipes": 0.296-0.299 ms per step of the
+ * headline bank against 0.260-0.276 in the default, immediate mode); a pipelined pipe also keeps the stream-order arrangement
+ * (context option "rx_direct" applies to immediate pipes). */
 int sdrhip_rx_set_pipelined(sdrhip_rx *rx, int on);
 int sdrhip_rx_flush(sdrhip_rx *rx, uint8_t *frames_out, size_t frame_stride_bytes, size_t *n_frames, int mem);
 /* the decimator launch of the last sdrhip_rx_process call (see sdrhip_decimators_last_plan) */
