@@ -42,6 +42,9 @@ __host__ __device__ constexpr int sbase(int n) { return KN + (KN - n); }        
 // already on their way from LDS (round 4: with load + wait inside every leaf a wave spent most of its time in s_waitcnt --
 // SQ_WAIT_ANY 57 % of the decoder's wave cycles, `tools/experiments_r04/exp14.sh` -- four waves per SIMD do not cover 162
 // dependent LDS round trips per walk)
+// (The loads are started in one asm statement and awaited in a later one; the hardware does not interlock registers that wait for LDS
+// data, so nothing may touch them in between: tools/check_asm_tables.py -- tests/test_asm_guard.py -- proves that on the compiled
+// assembly of every kernel, for this walk and for the additive-FFT one.)
 struct LeafRegs {
     uint4_t ta[2], tb[2];
     unsigned tca[2], tcb[2];
