@@ -482,8 +482,9 @@ def strong_layout_at_one_gpu(ctx, dev, n, kind, total=64):
 
 
 def interp_kernel_name(ctx):
-    """interpolate16_cen: K5w (interp_wave.h) unless the context was told otherwise (SDRHIP_INTERP_PATH = valu: K5)"""
-    return "interp_kernel<4>" if os.environ.get("SDRHIP_INTERP_PATH", "auto") == "valu" else "interp_wave_kernel<4, 4>"
+    """interpolate16_cen: K5w (interp_wave.h) unless the CONTEXT was told otherwise (set_option or the SDRHIP_INTERP_PATH it read
+    when it was created: valu = K5)"""
+    return "interp_kernel<4>" if ctx.option("interp_path", "auto") == "valu" else "interp_wave_kernel<4, 4>"
 
 
 def verify_tx_step(ctx, rxf, kind, n, pipelined=False):

@@ -12,6 +12,7 @@ Shapes: one stream (n, 2); a bank of S streams (S, n, 2).  There is no CPU imple
 behind these classes: without libsdrhip.so or without a GPU they raise.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -49,6 +50,7 @@ class Context:
         elif stream is not None and hasattr(stream, "cuda_stream"):
             stream = stream.cuda_stream
         self.h = C.c_void_p()
+        self.options = {}
         check(self.lib.sdrhip_ctx_create(device, C.c_void_p(stream or 0), C.byref(self.h)))
 
     def synchronize(self):
@@ -58,6 +60,14 @@ class Context:
         """kernel-path knobs for tests and tools (sdrhip_ctx_set_option): decim_path, mfma_span, mfma_min, interp_path,
         interp_span, rx_fused; the defaults were read from the SDRHIP_* environment when the context was created"""
         check(self.lib.sdrhip_ctx_set_option(self.h, str(key).encode(), str(value).encode()))
+        self.options[str(key)] = str(value)
+
+    def option(self, key, default=None):
+        """what this Context was last TOLD for `key`: by set_option, else by the SDRHIP_<KEY> environment variable that the library
+        read when the context was created, else `default` (the library's own default is not queried)"""
+        if key in self.options:
+            return self.options[key]
+        return os.environ.get("SDRHIP_" + str(key).upper(), default)
 
     def host_alloc(self, shape, dtype=np.int16):
         """numpy array on pinned host memory of the library (sdrhip_host_alloc): blocks submitted from it are uploaded in
