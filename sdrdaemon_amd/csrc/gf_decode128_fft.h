@@ -53,7 +53,7 @@ template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const De
     const __amdgpu_buffer_rsrc_t rrx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.rx) + (size_t)fr * a.rx_frame_bytes + 4, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rpay = __builtin_amdgcn_make_buffer_rsrc(a.payload_out + (size_t)fr * a.payload_frame_bytes, 0, 0x7fffffff, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    unsigned d[64];
+    unsigned d[64], e[16];
     {
         const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
         const bool live = col < 127u;
@@ -66,40 +66,56 @@ template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const De
             const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rrx, lc4, (pos < 0 ? 0 : pos & 127) * 512, 0); // (erased: some block that exists)
             d[i] = pos < 0 ? 0u : v;
         }
-        // the received originals go to their places (getSlotData's layout: blocks 1..127 back to back, block 0 apart)
+        // the received originals go to their places (getSlotData's layout: blocks 1..127 back to back, block 0 apart) -- the first
+        // 32 of the wave's blocks here, the other 32 between the two halves of the transform (fft_rows16's hook: they may still be
+        // on their way while the first half runs)
+        auto copy_out = [&](auto first, auto last) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const int j = b0 + i; // (uniform)
-            const int pos = __builtin_amdgcn_readfirstlane((int)pl->inv[j]);
-            if (pos < 0) continue; // (uniform; nothing is defined in here: no join of register values)
-            if (i == 0 && hf == 0) {
-                if (a.block0_out && live) reinterpret_cast<unsigned *>(a.block0_out + (size_t)fr * 508)[col] = d[0];
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b32(d[i], rpay, st4, (j - 1) * 508, 0);
+            for (int i = decltype(first)::value; i < decltype(last)::value; ++i) {
+                const int j = b0 + i; // (uniform)
+                const int pos = __builtin_amdgcn_readfirstlane((int)pl->inv[j]);
+                if (pos < 0) continue; // (uniform; nothing is defined in here: no join of register values)
+                if (i == 0 && hf == 0) {
+                    if (a.block0_out && live) reinterpret_cast<unsigned *>(a.block0_out + (size_t)fr * 508)[col] = d[0];
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(d[i], rpay, st4, (j - 1) * 508, 0);
+                }
             }
+        };
+        if (N == 0 || m1) { // (copy only / cm256's DecodeM1; workgroup-uniform, in front of the barriers; this path ENDS here: no join)
+            copy_out(std::integral_constant<int, 0>{}, std::integral_constant<int, 64>{});
+            if (N == 0) return;
+            // cm256's DecodeM1: one recovery block, the erased original is the XOR of everything received (Minv = 1)
+            unsigned par = 0u;
+#pragma unroll
+            for (int i = 0; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
+            (xch0 + lane)[(32 + hf) * 64] = par;
+            __syncthreads();
+            if (hf == 0) {
+                const unsigned P = (xch0 + lane)[32 * 64] ^ (xch0 + lane)[33 * 64];
+                const int rp = __builtin_amdgcn_readfirstlane((int)pl->rpos[0]) & 127;
+                const unsigned rec = __builtin_amdgcn_raw_buffer_load_b32(rrx, lc4, rp * 512, 0);
+                const int yy = __builtin_amdgcn_readfirstlane((int)pl->ydst[0]), y = yy & 0x7f;
+                const unsigned val = (yy & 0x80) ? 0u : (P ^ rec); // (strict mode: a block the reference's copy-back would miss stays a hole)
+                if (y >= 1) __builtin_amdgcn_raw_buffer_store_b32(val, rpay, st4, (y - 1) * 508, 0);
+                else if (a.block0_out && live) reinterpret_cast<unsigned *>(a.block0_out + (size_t)fr * 508)[col] = val;
+            }
+            return;
         }
-        if (N == 0) return; // (copy only; workgroup-uniform, in front of the barriers)
+        copy_out(std::integral_constant<int, 0>{}, std::integral_constant<int, 32>{});
         unsigned par = 0u;
 #pragma unroll
-        for (int i = 0; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
-        (xch0 + lane)[(32 + hf) * 64] = par;
+        for (int i = 0; i < 32; i += 2) par = x3(par, d[i], d[i + 1]);
+        fft_rows16<HF>(d, e, la, xch0, [&]() __attribute__((always_inline)) {
+            copy_out(std::integral_constant<int, 32>{}, std::integral_constant<int, 64>{});
+#pragma unroll
+            for (int i = 32; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
+            (xch0 + lane)[(32 + hf) * 64] = par;
+        });
     }
 
     unsigned *const syn = xch0; // [i][lane]
-    if (m1) {
-        // cm256's DecodeM1: one recovery block, the erased original is the XOR of everything received
-        __syncthreads();
-        if (hf == 0) {
-            const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
-            const unsigned P = (xch0 + lane)[32 * 64] ^ (xch0 + lane)[33 * 64];
-            const int rp = __builtin_amdgcn_readfirstlane((int)pl->rpos[0]) & 127;
-            const unsigned rec = __builtin_amdgcn_raw_buffer_load_b32(rrx, col < 127u ? 4u * col : OOB, rp * 512, 0);
-            (syn + lane)[0] = col < 127u ? (P ^ rec) : 0u;
-        }
-        __syncthreads();
-    } else {
-        unsigned e[16];
-        fft_rows16<HF>(d, e, la, xch0);
+    {
         // syndromes of the received recovery rows among rows 16 hf .. 16 hf + 15: recovery ^ (P ^ (r c / q) * value_r)
         const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
         const unsigned ld4 = col < 127u ? 4u * col : OOB;

@@ -89,20 +89,34 @@ __device__ __forceinline__ unsigned fft_lane()
 template <class F, int... Is> __device__ __forceinline__ void fft_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void fft_for(F &&f) { fft_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-// block n = 0..62 of the size-64 inverse transform: stage k = 0..5 has 32 >> k blocks, table n (+ 63 for the second half)
-__host__ __device__ constexpr int fft_inv_stage(int n) { int k = 0; while (n >= 64 - (64 >> (k + 1))) ++k; return k; }
+// The 63 blocks of the size-64 inverse transform in DEPTH-FIRST order: position n = 0..30 = stages 0..4 of elements 0..31, n = 31..61 the
+// same for elements 32..63, n = 62 the one block of stage 5.  (Breadth first -- all of stage 0 first -- the network needs all 64 values
+// before its first butterfly is through; this way the first half runs while the second half's loads are still on their way, and the
+// caller's `mid` hook -- stores and parity of the second half -- sits between the halves.)  Stage k of the whole transform has 32 >> k
+// blocks, block j works on elements [2 j 2^k, 2 (j + 1) 2^k) with table 64 - (64 >> k) + j (+ 63 for the second block half).
+struct FftBlk { int k, j; };
+__host__ __device__ constexpr FftBlk fft_inv_block(int n)
+{
+    if (n >= 62) return FftBlk{5, 0};
+    const int g = n / 31, p = n % 31;
+    int k = 0;
+    while (k < 4 && p >= 32 - (32 >> (k + 1))) ++k; // (a group of 32 elements: 16 >> k blocks in stage k, 32 - (32 >> k) in front of it)
+    return FftBlk{k, g * (16 >> k) + (p - (32 - (32 >> k)))};
+}
+__host__ __device__ constexpr int fft_inv_table(int n) { return n >= 63 ? 126 : 64 - (64 >> fft_inv_block(n).k) + fft_inv_block(n).j; }
 
 // inverse transform of size 64 (values on the coset 64 hf + V6 -> novel-basis coefficients) and the t5 fold: d[0..31] = the half's
-// 32 coefficients on 128 + V5.  lh: LDS address of table 0 of this half; la: of table 0.
-template <int HF> __device__ __forceinline__ void fft_inverse64_fold(unsigned (&d)[64], unsigned lh, unsigned la)
+// 32 coefficients on 128 + V5.  lh: LDS address of table 0 of this half; la: of table 0.  mid(): called between the two halves of 32.
+template <int HF, class MID> __device__ __forceinline__ void fft_inverse64_fold(unsigned (&d)[64], unsigned lh, unsigned la, MID &&mid)
 {
     FftTabs R;
-    fft_issue<0, 0>(R, lh);
-    fft_issue<1, 1>(R, lh);
+    fft_issue<0, fft_inv_table(0)>(R, lh);
+    fft_issue<1, fft_inv_table(1)>(R, lh);
     fft_for<63>([&](auto nc) __attribute__((always_inline)) {
-        constexpr int n = decltype(nc)::value, k = fft_inv_stage(n), h = 1 << k, j = n - (64 - (64 >> k)), blk = j * 2 * h, P = n % 3;
-        fft_wait_ahead<P>(R); // (block n + 1's table -- t5 behind the last block -- is on its way)
-        if constexpr (n + 2 < 63) fft_issue<(n + 2) % 3, n + 2>(R, lh);
+        constexpr int n = decltype(nc)::value, k = fft_inv_block(n).k, j = fft_inv_block(n).j, h = 1 << k, blk = j * 2 * h, P = n % 3;
+        if constexpr (n == 31) mid();
+        fft_wait_ahead<P>(R); // (position n + 1's table -- t5 behind the last block -- is on its way)
+        if constexpr (n + 2 < 63) fft_issue<(n + 2) % 3, fft_inv_table(n + 2)>(R, lh);
         else if constexpr (n + 2 == 63) fft_issue<(n + 2) % 3, 126>(R, la); // t5
 #pragma unroll
         for (int i = 0; i < h; ++i) d[blk + h + i] ^= d[blk + i];
@@ -168,11 +182,11 @@ __device__ __forceinline__ void fft_fill_tables(const Enc128Args &a, unsigned ch
 // HF is a template parameter: the two block halves run different code (the first half's stages begin with a block whose constant
 // is zero -- 63 of its 224 multiplications -- and the exchange is not symmetric); as a run-time value the skipped blocks became
 // branches inside the network and the register allocator spilled at every join.
-template <int HF> __device__ __forceinline__ void fft_rows16(unsigned (&d)[64], unsigned (&e)[16], unsigned la, unsigned *xch0)
+template <int HF, class MID> __device__ __forceinline__ void fft_rows16(unsigned (&d)[64], unsigned (&e)[16], unsigned la, unsigned *xch0, MID &&mid)
 {
     constexpr int hf = HF;
     FFT_STAMP(2);
-    fft_inverse64_fold<HF>(d, la + (unsigned)(hf * 63 * 32), la);
+    fft_inverse64_fold<HF>(d, la + (unsigned)(hf * 63 * 32), la, mid);
     FFT_STAMP(3);
     unsigned *const xch = xch0 + fft_lane();
     if constexpr (hf == 0) {
@@ -300,14 +314,17 @@ template <int HF> __device__ __forceinline__ void gf_encode128_fft_wave(const En
 #pragma unroll
         for (int i = 0; i < 64; ++i) __builtin_amdgcn_raw_buffer_store_b32(d[i], rf, lc4, (b0 + i) * 512, 0);
     }
-    {
-        unsigned par = 0u;
+    // parity: of the first 32 values here, of the other 32 between the two halves of the transform (they may still be on their way
+    // while the first half runs); both block halves' parities wait in LDS: one long-lived register less
+    unsigned par = 0u;
 #pragma unroll
-        for (int i = 0; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
-        (xch0 + lane)[(32 + hf) * 64] = par; // (both halves' parities wait in LDS: one long-lived register less)
-    }
+    for (int i = 0; i < 32; i += 2) par = x3(par, d[i], d[i + 1]);
     unsigned e[16];
-    fft_rows16<HF>(d, e, la, xch0);
+    fft_rows16<HF>(d, e, la, xch0, [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 32; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
+        (xch0 + fft_lane())[(32 + hf) * 64] = par;
+    });
     // rows 16 hf + i
     {
         FftTabs R;
