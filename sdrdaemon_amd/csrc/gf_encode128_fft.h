@@ -19,7 +19,7 @@
 //      16 + r, behind it the two halves of 16 are independent;
 //   4. recovery_r = P ^ (r c / q) * value_r.
 // 384 - 63 (the leading block of every stage of the first half has the constant 0: skipped) + 64 + 32 + 80 + 32 = 529 constant
-// multiplications and ~1200 XORs per column: ~45 % of the instructions of the Karatsuba walk (measured: 13.9 M against 25.6 M
+// multiplications and ~1200 XORs per column: ~45 % of the instructions of the Karatsuba walk (measured: 12.6 M against 25.6 M
 // VALU wave-instructions per 1040 frames).
 // (tools/experiments_r05/lch_encode_proto.py is the same algorithm in numpy, checked against the oracle's cm256_encode.)
 //
@@ -29,7 +29,7 @@
 // to the hf = 1 wave through LDS (barrier), that one applies t6 and the first stage of the size-32 transform and hands rows
 // 0..15 back (barrier); then each wave finishes a size-16 transform and 16 recovery rows.  A frame = 4 waves instead of the
 // first version's 2 (a wave = a frame half with all 128 blocks: 96 live values, spilled at 128 registers, and 2080 waves of
-// 14 us each on 1024 SIMDs is a two-and-a-bit-round launch); 1040 workgroups of 64 registers x 4 waves sit four to a CU.
+// 14 us each on 1024 SIMDs is a two-and-a-bit-round launch); 95 registers, 23.5 KB of LDS: four to five workgroups per CU.
 #pragma once
 
 constexpr int FFT_NTAB = 192;                       // gf256.h: CM256_FFT_TABLES
@@ -39,10 +39,11 @@ constexpr int FFT_XCH_DWORDS = 32 * 64 + 2 * 64;
 constexpr int ENC128_FFT_LDS_BYTES = FFT_TAB_BYTES + 2 * FFT_XCH_DWORDS * 4;
 constexpr int FFT_MAX_ROWS = 32;
 #ifndef FFT_WAVES_PER_EU
-#define FFT_WAVES_PER_EU 4 // (5 = 96 registers measured the same until the tables ran two blocks ahead: the third set does not fit in 96)
+#define FFT_WAVES_PER_EU 4 // (the compiler's register budget: 128; the kernel takes 95, so five waves per SIMD are resident where the LDS allows)
 #endif
 
-// The multiplier tables travel through two register sets: while block n is multiplied, the table of block n + 1 is on its way from
+// The multiplier tables travel through two or three register sets: while block n is multiplied, the table of block n + 1 (inverse
+// transform: and n + 2) is on its way from
 // LDS (the experience of the Karatsuba walk, gf_encode128_body.h: left to the compiler every table load of the unrolled network is
 // hoisted to the top -- immediate addresses, no dependencies -- and the registers spill; with load + wait inside every block the
 // wave waits ~100 cycles 190 times).  asm statements keep the loads in program order; the wait statement re-defines the registers
