@@ -826,6 +826,9 @@ def main():
         # the state of the box the line was measured on: both dominant kernels are limited by the board's power cap,
         # so ms_per_step on another box scales with what that box's silicon and cooling make of the cap
         res["box"] = box_state
+        if isinstance(box_state, dict) and box_state.get("power_w"):
+            # energy of one step at the sampled socket power: the figure kernel changes are judged by on a power-limited box
+            res["box"]["energy_mj_per_step"] = round(float(box_state["power_w"]) * res["ms_per_step"], 1)
         lane_ops = pmc_valu_lane_ops(per_launch_samples, kname)
         if lane_ops and dec_n:
             # secondary figure of SURVEY.md 8(d): integer VALU issue, every op counted at the 16-lane / clk rate
