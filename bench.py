@@ -346,6 +346,24 @@ def extra_configs(ctx, dev, x, kind, ids):
                                  pmc_traffic(float(S) * n, decim_kernel_name(d.last_plan()))),
                 "verified": verify_decim(ctx, x, ids, kind)})
     del y, d
+    # the headline workload in the round-4 ARRANGEMENT (rx_direct = 0): the matrix-core decimator stores in stream order, K2 and the
+    # encoder's fused copy frame it (three roles, two launches).  Same frames; the decimator alone is faster there (its writes are
+    # 67 MB that stay in the Infinity Cache), the encoder slower (it carries the copy), the step about the same, the traffic 134 MB more.
+    from sdrdaemon_amd.engine import K_FEC_ENCODE
+    ctx.set_option("rx_direct", 0)
+    try:
+        rxs = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                        center_frequency_khz=435000, sample_rate=625000)
+        wall, per = timed_steps(ctx, lambda: rxs.process_view(x, tv_sec=1, tv_usec=0), [K_DECIMATE, K_FEC_ENCODE])
+        del rxs
+        out.append({"config": "configs[2] x %d streams, stream-order arrangement (rx_direct = 0): decimator output in stream order, framing by K2 + the "
+                              "encoder's fused copy (gf_encode128_fft_pack_kernel)" % S,
+                    "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
+                    "fec_encode_avg_launch_ms": round(per[K_FEC_ENCODE], 4),
+                    "roofline": roof(BYTES_DECIM * S * n, per[K_DECIMATE], "decim_mfma_kernel<4,true> (stream-order stores)"),
+                    "verified": verify_step(ctx, x, ids, kind)})
+    finally:
+        ctx.set_option("rx_direct", 1)
     # the headline workload through the pipelined plumbing (sdrhip_rx_set_pipelined: frames delivered one call late).  Two variants of
     # where the waiting encode runs: inside the decimator launch of the next call (rx_fused_kernel), or as its own launch on the
     # context's second stream BESIDE that decimator (LDS-DMA ring of depth 3 so that two encoder workgroups fit on every CU).
