@@ -44,6 +44,7 @@ import torch  # noqa: E402
 STREAMS_PER_GPU = 8
 LOG2DECIM, NB_FEC = 4, 32
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+PCIE_PEAK_GBS = 63.0   # host link, PCIe Gen5 x16 per direction (same guide): the bound of the host-fed (drop-in) mode
 # algorithmic bytes per input sample
 BYTES_DECIM = 4.0 + 4.0 / 16.0                      # kernel K1: read int16 IQ, write 1/16 of it
 BYTES_CONFIG3 = 4.0 + 160.0 * 512.0 / 258064.0      # whole pipe incl. the 160 x 512 B frames
@@ -161,9 +162,11 @@ def make_input(ctx, device, n, seeds, kind):
         return torch.stack(out)
     import sdrdaemon_amd as sd
 
+    import headline_inputs as hi
+
     ts = sd.TestSource(ctx, len(seeds))
     for s, seed in enumerate(seeds):
-        assert ts.configure("srate=10000000,dfp=%d,power=20" % (100000 + 1000 * (seed % 1000)), s), ts.error()
+        assert ts.configure(hi.ts_config_string(seed), s), ts.error()
     x = ts.read(n)
     ctx.synchronize()
     return x.reshape(len(seeds), n, 2).contiguous()
@@ -346,6 +349,27 @@ def extra_configs(ctx, dev, x, kind, ids):
                                  pmc_traffic(float(S) * n, decim_kernel_name(d.last_plan()))),
                 "verified": verify_decim(ctx, x, ids, kind)})
     del y, d
+    # the headline step on the input every BASELINE config names: TestSource (10 Msps CW; the bank's integer NCO on the device,
+    # tests/headline_inputs.py), verified against digests made in the build container by the compiled reference decimator over the
+    # oracle's restatement of that NCO (headline_golden.json ts_bank8).  A CW carrier 20 dB under full scale toggles far fewer bits
+    # than full-scale noise: on kernels that sit at the board's power cap the bit pattern is part of the result.
+    if kind != "testsource":
+        xt = make_input(ctx, dev, n, [1000 + sid for sid in ids], "testsource")
+        rxt = sd.RxPipe(ctx, S, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                        center_frequency_khz=435000, sample_rate=625000)
+        from sdrdaemon_amd.engine import K_FEC_ENCODE as _KFE
+        wall, per = timed_steps(ctx, lambda: rxt.process_view(xt, tv_sec=1, tv_usec=0), [K_DECIMATE, _KFE])
+        plan_t = rxt.last_plan()
+        del rxt
+        import headline_inputs as _hi
+        out.append({"config": "configs[2] x %d streams on TestSource input: %s ... (the bank's integer NCO, generated on the device), decimate16_cen + framing + "
+                              "CM256 128+32 -- the headline step, other bit pattern" % (S, _hi.ts_config_string(1000 + ids[0])),
+                    "ms_per_step": round(wall, 4), "value": round(S * n / wall / 1e3, 1), "unit": "Msamples/s (input)",
+                    "fec_encode_avg_launch_ms": round(per[_KFE], 4),
+                    "roofline": roof(BYTES_DECIM * S * n, per[K_DECIMATE], decim_kernel_name(plan_t)),
+                    "path_frac": round(BYTES_CONFIG3 * S * n / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "verified": verify_step(ctx, xt, ids, "testsource")})
+        del xt
     # the headline workload in the round-4 ARRANGEMENT (rx_direct = 0): the matrix-core decimator stores in stream order, K2 and the
     # encoder's fused copy frame it (three roles, two launches).  Same frames; the decimator alone is faster there (its writes are
     # 67 MB that stay in the Infinity Cache), the encoder slower (it carries the copy), the step about the same, the traffic 134 MB more.
@@ -439,7 +463,91 @@ def extra_configs(ctx, dev, x, kind, ids):
                 "roofline": roof((4.0 + 128.0 * 512.0 / 258064.0) * nout, wall, interp_kernel_name(ctx) + " || gf_decode128_fft_kernel (config-4 algorithmic "
                                  "bytes, 4.254 B per output; the launches overlap, the step's wall time is the launch time)"),
                 "verified": txp_verified})
+    out.extend(drop_in_lines(ctx))
     return out
+
+
+def drop_in_lines(ctx):
+    """The drop-in (host-fed) mode as sdrdaemonrx drives it (VERDICT r5 #3b): one TestSource block of 65 536 samples per call
+    (TestSource.h:33) handed over as a HOST buffer (sdrdaemonrx.cpp:590,640) -- PCIe-inclusive, host to host, through the Python
+    mirror of the adapters (ctypes adds ~2 us per call over the C++ headers).  Three shapes: Downsampler::process (decimate16_cen
+    alone, synchronous), the Rx pipe synchronous (decimate + framing + CM256 128+32), and the asynchronous entry
+    (sdrhip_rx_submit / sdrhip_rx_collect) with 16 blocks per upload + launch + download, three batches in flight.
+    Bound: the host link (4 bytes in per input sample + 0.317 out)."""
+    import sdrdaemon_amd as sd
+
+    nblk = 65536
+    rng = np.random.default_rng(77)
+    x = rng.integers(-32768, 32768, (nblk, 2), dtype=np.int16)
+    lines = []
+
+    def line(config, us_per_block, nbytes, extra=None):
+        gbs = nbytes / (us_per_block * 1e-6) / 1e9
+        d = {"config": config, "us_per_block": round(us_per_block, 2), "value": round(nblk / us_per_block, 1), "unit": "Msamples/s (input, host to host)",
+             "roofline": {"bound": "pcie", "achieved": round(gbs, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / PCIE_PEAK_GBS, 4),
+                          "peak_source": "PCIe Gen5 x16, 63 GB/s per direction (MI355X_MICROARCH.md, host link)", "traffic": None}}
+        if extra:
+            d.update(extra)
+        lines.append(d)
+
+    # (a) Downsampler::process: decimate16_cen of one block, synchronous
+    d = sd.Decimators(ctx, 1, sd.HB_EO1)
+    for _ in range(100):
+        d.decimate(LOG2DECIM, sd.FC_CEN, 16, x)
+    K = 500
+    t0 = time.perf_counter()
+    for _ in range(K):
+        d.decimate(LOG2DECIM, sd.FC_CEN, 16, x)
+    us = (time.perf_counter() - t0) / K * 1e6
+    line("drop-in, configs[1] shape: Downsampler::process on one 65 536-sample host block per call (decimate16_cen, synchronous, host pointers)", us,
+         nblk * BYTES_DECIM, {"kernel_path": d.last_plan()["path"]})
+    del d
+    # (b) the Rx pipe on one block per call, synchronous
+    rx = sd.RxPipe(ctx, 1, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                   center_frequency_khz=435000, sample_rate=625000)
+    for _ in range(100):
+        rx.process(x, 1, 2)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        rx.process(x, 1, 2)
+    us = (time.perf_counter() - t0) / K * 1e6
+    line("drop-in, configs[2] shape: sdrhip_rx_process on one 65 536-sample host block per call (decimate16_cen + framing + CM256 128+32, synchronous)", us,
+         nblk * BYTES_CONFIG3)
+    del rx
+    # (c) the asynchronous entry: 16 blocks per batch from pageable memory, the collector one batch behind
+    blocks, nb = 16, 16 * 16
+    src = rng.integers(-32768, 32768, (1, nb * nblk, 2), dtype=np.int16)
+    rx = sd.RxPipe(ctx, 1, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                   center_frequency_khz=435000, sample_rate=625000)
+    rx.set_async(depth=4, blocks=blocks)
+    blks = [src[:, b * nblk:(b + 1) * nblk] for b in range(nb)]
+    maxf = blocks * nblk // (16129 * 16) + 2
+
+    def run(rounds):
+        inflight, frames = 0, 0
+        for _ in range(rounds):
+            for b in range(nb):
+                rx.submit(blks[b], 1, 2)
+                if (b + 1) % blocks == 0:
+                    inflight += 1
+                    if inflight == 3:
+                        frames += rx.collect(wait=True, max_frames=maxf).shape[1]
+                        inflight -= 1
+        while inflight:
+            frames += rx.collect(wait=True, max_frames=maxf).shape[1]
+            inflight -= 1
+        return frames
+
+    run(1)
+    R = 6
+    t0 = time.perf_counter()
+    frames = run(R)
+    us = (time.perf_counter() - t0) / (R * nb) * 1e6
+    assert abs(frames - R * nb * nblk // (16 * 16129)) <= 1, frames  # (every submitted sample came back framed)
+    line("drop-in, configs[2] shape, asynchronous entry: sdrhip_rx_submit / sdrhip_rx_collect, 65 536-sample host blocks (pageable), %d blocks per "
+         "upload + launch + download, 3 batches in flight" % blocks, us, nblk * BYTES_CONFIG3, {"frames_collected": int(frames)})
+    del rx
+    return lines
 
 
 def verify_one_stream(ctx, x1, kind):
@@ -551,12 +659,15 @@ def verify_tx_step(ctx, rxf, kind, n, pipelined=False):
             "against": "the dense decoder path of this library on the same input (no committed digest for this geometry)"}
 
 
-def _gold_bank(n, ids):
-    """the committed reference digests (tests/golden/headline_golden.json) of the bank that holds exactly these streams, or None"""
+def _gold_bank(n, ids, kind="hash"):
+    """the committed reference digests (tests/golden/headline_golden.json) of the bank that holds exactly these streams of this input
+    kind (hash: counter-based noise; testsource: the TestSource bank's NCO, made by the oracle's restatement of it), or None"""
+    if kind not in ("hash", "testsource"):
+        return None, None
     try:
         with open(os.path.join(ROOT, "tests", "golden", "headline_golden.json")) as f:
             H = json.load(f)
-        for name in ("bank8", "bank64_25", "bank64"):
+        for name in (("bank8", "bank64_25", "bank64") if kind == "hash" else ("ts_bank8",)):
             b = H[name]
             if (1 << b["log2n"]) == n and all((1000 + sid) in b["seeds"] for sid in ids):
                 return b, [b["seeds"].index(1000 + sid) for sid in ids]
@@ -585,7 +696,7 @@ def verify_decim(ctx, x, ids, kind):
             ctx.set_option("decim_path", "auto")
 
     got, path = digests("auto")
-    b, idx = _gold_bank(n, ids) if kind == "hash" else (None, None)
+    b, idx = _gold_bank(n, ids, kind)
     what = "sha256 of every stream's whole decimated output of one step"
     if b is not None:
         return {"ok": got == [b["dec_sha256"][i] for i in idx], "streams": S, "kernel_path": path, "what": what,
@@ -622,12 +733,12 @@ def verify_step(ctx, x, ids, kind, pipelined=False):
 
     got, path = frames_digests("auto")
     gold = None
-    if kind == "hash":
-        b, idx = _gold_bank(n, ids)
-        if b is not None:
-            gold = [b["frames_sha256"][i] for i in idx]
+    b, idx = _gold_bank(n, ids, kind)
+    if b is not None:
+        gold = [b["frames_sha256"][i] for i in idx]
     if gold is not None:
-        return {"ok": got == gold, "against": "tests/golden/headline_golden.json (compiled reference decimate16_cen + framer / CM256 restatement)",
+        return {"ok": got == gold, "against": "tests/golden/headline_golden.json %s(compiled reference decimate16_cen + framer / CM256 restatement)" %
+                                              ("ts_bank8: the TestSource NCO samples by the oracle " if kind == "testsource" else ""),
                 "streams": S, "kernel_path": path, "what": "sha256 of every stream's whole frame stream of one step"}
     exp, _ = frames_digests("valu")
     return {"ok": got == exp, "against": "the VALU kernel path of this library on the same input (no committed digest for this geometry)",
@@ -676,8 +787,9 @@ def main():
     ap.add_argument("--preroll-seconds", type=float, default=0.25,
                     help="untimed run-in of the same step before the W warm-up steps (the GPU's clocks ramp over the first "
                          "~60 ms of load: with a small W the timed steps would measure that ramp)")
-    ap.add_argument("--timer-stride", type=int, default=4,
-                    help="the HIP-event timers of the roofline kernel bracket every N-th step of the timed region (default 4)")
+    ap.add_argument("--timer-stride", type=int, default=0,
+                    help="the HIP-event timers of the roofline kernel bracket every N-th step of the timed region (default: 4, and 1 -- "
+                         "every launch -- when --steps < 50, so that the kernel average of a short run rests on all of its launches)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: leave the per-kernel HIP events out of the timed region (roofline fields become null)")
     ap.add_argument("--no-box-state", action="store_true", help="do not sample socket power / shader clock (amdsmi) beside the timed region")
@@ -687,6 +799,8 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to dry-run the N > 1 path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
+    if args.timer_stride <= 0:
+        args.timer_stride = 1 if args.steps < 50 else 4
     if args.streams is None:
         # SDRHIP_BENCH_SCALE=1: this run is one point of a 1 / 2 / 4 / 8 sweep -- the N = 1 point is then the SAME job as the
         # others (SURVEY 8e's bank of 64 streams); without it the one-GPU run is the headline step (8 streams, config 5's per-GPU

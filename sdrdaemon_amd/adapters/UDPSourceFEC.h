@@ -230,14 +230,22 @@ private:
             for (std::deque<Ready>::iterator it = m_ready.begin(); it != m_ready.end(); ++it) it->pending = false;
             return;
         }
-        const std::vector<unsigned long> seqs = m_batches.front();
-        m_batches.pop_front();
+        const std::vector<unsigned long> seqs = m_batches.front(); // (popped only once the library has consumed ITS oldest batch)
         const size_t per = (size_t)(NB - 1) * BLOCK; // bytes of payload per frame = 16129 samples
         std::vector<unsigned char> payload(seqs.size() * per), b0(seqs.size() * (size_t)BLOCK);
         size_t n_out = 0, nf = 0;
         const int rc = sdrhip_tx_collect(m_tx, reinterpret_cast<int16_t *>(&payload[0]), 0, payload.size() / 4, &b0[0], &n_out, &nf, 1);
-        const bool ok = rc == SDRHIP_OK && nf == seqs.size() && n_out * 4 == payload.size();
-        if (!ok) std::cerr << "SDRdaemonFECBuffer::writeAndRead: CM256 decode error (" << sdrhip_last_error() << ")" << std::endl;
+        if (rc != SDRHIP_OK) {
+            // the library's batch is still at the head of ITS ring (a collect that fails consumes nothing): dropping only our entry would
+            // pair every later collect with the wrong frames.  Every batch in flight is given up (the frames keep what was received)
+            // and the handle is replaced, so that the two rings start over in step.
+            std::cerr << "SDRdaemonFECBuffer::writeAndRead: CM256 decode error (" << sdrhip_last_error() << ")" << std::endl;
+            resetTx();
+            return;
+        }
+        m_batches.pop_front();
+        const bool ok = nf == seqs.size() && n_out * 4 == payload.size();
+        if (!ok) std::cerr << "SDRdaemonFECBuffer::writeAndRead: CM256 decode error (batch of " << nf << " frames for " << seqs.size() << ")" << std::endl;
         for (size_t g = 0; g < seqs.size(); ++g) {
             if (seqs[g] < m_seqFront) continue; // (handed out already: cannot happen, frames wait for their batch)
             Ready &r = m_ready[seqs[g] - m_seqFront];
@@ -245,6 +253,20 @@ private:
             if (!ok) continue; // the frame keeps what was received
             std::memcpy(&r.frame[0], &b0[g * BLOCK], BLOCK);
             std::memcpy(&r.frame[BLOCK], &payload[g * per], per);
+        }
+    }
+
+    // give up every batch in flight and replace the library handle (collectBatch: a collect that failed without consuming its batch)
+    void resetTx()
+    {
+        for (std::deque<Ready>::iterator it = m_ready.begin(); it != m_ready.end(); ++it) it->pending = false;
+        m_batches.clear();
+        if (m_tx) sdrhip_tx_destroy(m_tx);
+        m_tx = 0;
+        if (m_ctx && (sdrhip_tx_create(m_ctx, 1, 0, &m_tx) != SDRHIP_OK || sdrhip_tx_set_async(m_tx, MAXINFLIGHT) != SDRHIP_OK)) {
+            std::cerr << "UDPSourceFEC: cannot re-create the decoder (" << sdrhip_last_error() << "): frames are delivered as received" << std::endl;
+            if (m_tx) sdrhip_tx_destroy(m_tx);
+            m_tx = 0;
         }
     }
 

@@ -128,6 +128,7 @@ struct CtxOptions {
     // Rx pipe on the matrix-core decimator: 1 = its waves store straight into the frame layout (round 5: no stream-order buffer, no
     // framing copy in the encoder, no K2 launch), 0 = stream order + K2 + the encoder's fused copy (the round-3 arrangement)
     int rx_direct = 1;
+    int rx_window = 0;                     // frame window of the Rx pipe in calls (1..8); 0 = the default: 2, pipelined pipes 4 (sdrhip_rx_process)
     int tx_overlap = 1;                    // pipelined Tx pipe: 1 = decode of this batch on the second stream beside the interpolator of the previous one, 0 = one stream
     int enc_fft = 1;                       // structured 128-original encoder, rows <= 32: additive FFT (1) or the Karatsuba XOR-convolution walk (0)
     int enc_min_rows = 1;                  // ... the FFT from this many recovery blocks on (the generic matrix kernel below)

@@ -177,6 +177,7 @@ struct sdrhip_rx {
     };
     std::vector<Batch> abatch;
     int a_blocks = 1;             // blocks per launch
+    bool consumed = false;        // set by sdrhip_rx_process once the decimator launch of the call went out (the filter state advanced)
     size_t a_head = 0, a_tail = 0; // next batch to collect / batch being filled
 };
 
@@ -367,6 +368,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
     }
     if (!iq_in) return fail(SDRHIP_EINVAL, "rx_process: NULL input");
     sdrhip_ctx *c = rx->ctx;
+    rx->consumed = false;
     HIP_TRY(hipSetDevice(c->device));
     const int S = rx->nstreams, L = rx->cfg.log2decim, R = rx->cfg.nb_fec;
     const int FB = SDRHIP_NB_ORIGINAL + R;
@@ -421,10 +423,9 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
             // the window: TWO calls' frames (round 5; four until then).  The step rewrites what it wrote two calls ago: 2 x 84 MB per
             // 8-stream bank stay in the 256 MB of Infinity Cache, and on this memory system a write stream that stays there
             // costs the read stream beside it less (profiles/r05_rx_direct.txt: decimator launch 0.2435 -> 0.2335 ms, encoder
-            // launch 0.052 -> 0.049 ms; a window of one call wraps -- a copy of the open frames -- on every call).  SDRHIP_RX_WINDOW = A / B
+            // launch 0.052 -> 0.049 ms; a window of one call wraps -- a copy of the open frames -- on every call).  option rx_window (SDRHIP_RX_WINDOW at context creation, 1..8) = A / B
             // (pipelined pipes keep the previous call's frames until they are delivered: four calls, as before)
-            static const size_t wenv = getenv("SDRHIP_RX_WINDOW") ? (size_t)atoi(getenv("SDRHIP_RX_WINDOW")) : 0;
-            const size_t wmul = wenv ? wenv : rx->pipelined ? 4 : 2;
+            const size_t wmul = c->opt.rx_window ? (size_t)c->opt.rx_window : rx->pipelined ? 4 : 2;
             const size_t ncap = need > rx->cap_frames ? wmul * need : rx->cap_frames;
             if ((rc = bigger.reserve((size_t)S * ncap * frame_bytes))) return rc;
             if (rx->frame_open)
@@ -501,6 +502,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         if ((rc = lin.reserve((size_t)S * lstride * 4 + 16))) return rc;
         rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, lin.as<int16_t>(), lstride, &n_out, 0, 0, 0, nullptr, fuse, &fused, coresident);
         if (rc) return rc;
+        rx->consumed = true;
         if (fused) rx->late.encode = false;
         // the frames that lie entirely inside this call's samples are laid out by the encoder (fused copy); K2 does
         // the frame that was open when the call began, the one left open at its end, meta blocks and headers
@@ -535,6 +537,7 @@ extern "C" int sdrhip_rx_process(sdrhip_rx *rx, const int16_t *iq_in, size_t n_i
         rc = decimate_device(rx->dec, L, rx->cfg.fcpos, &ss, din, n_in, dstride, reinterpret_cast<int16_t *>(work), stream_bytes / 4, &n_out, 1,
                              FB, rx->pending_samples, &meta);
         if (rc) return rc;
+        rx->consumed = true;
     }
     if ((rc = rx_settle(rx))) return rc; // (a waiting encode that this call's launch could not take along)
 
@@ -656,16 +659,20 @@ int rx_launch_batch(sdrhip_rx *rx, sdrhip_rx::Batch &b)
         i = j;
     }
     b.in.mark(c->stream);
-    // everything that can fail for want of memory happens BEFORE the samples are consumed: a batch that failed here is launched again
-    // by the next submit / collect, one that fails behind sdrhip_rx_process is dropped (its samples are in the filter state already;
-    // replaying them would duplicate samples and shift every later stamp)
+    // everything that can fail for want of memory happens BEFORE the samples are consumed: a batch that failed here, or that
+    // sdrhip_rx_process refused before its decimator launch went out, is launched again by the next submit / collect; one that fails
+    // behind the decimator launch (rx->consumed) is dropped: its samples are in the filter state already, replaying them would
+    // duplicate samples and shift every later stamp
     b.frame_bytes = (size_t)(SDRHIP_NB_ORIGINAL + rx->cfg.nb_fec) * SDRHIP_UDPSIZE;
     const size_t nf_max = sdrhip_rx_max_frames(rx, b.n_in);
     if (nf_max && (rc = b.out.reserve((size_t)S * nf_max * b.frame_bytes))) return rc;
     if (!b.done && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) { b.done = nullptr; return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
     size_t nf = 0;
     rc = sdrhip_rx_process(rx, b.din.as<int16_t>(), b.n_in, dstride, b.tv_sec, b.tv_usec, nullptr, 0, &nf, SDRHIP_MEM_DEVICE);
-    if (rc) return rc; // (refused before any launch, or a launch failure: the pipe's own error)
+    if (rc) {
+        if (rx->consumed) b.state = 0; // consumed and lost: never replayed (the pipe's own error stands)
+        return rc;
+    }
     b.frames = nf;
     hipError_t e = hipSuccess;
     if (nf > nf_max) e = hipErrorInvalidValue; // (cannot happen: rx_max_frames is the pipe's own bound)
@@ -838,6 +845,7 @@ struct sdrhip_tx {
     DevBuf plan_own, idx_own;
     PinnedBuf pin_own;
     hipEvent_t ev_in = nullptr;              // first stream: the caller's device rx buffer is ready
+    hipEvent_t ev_up = nullptr;              // second stream: the upload of the caller's HOST rx buffer has read it (the call returns behind it)
     hipEvent_t ev_dec = nullptr;             // second stream: the waiting batch is decoded
     hipEvent_t ev_itp[2] = {nullptr, nullptr}; // first stream: the interpolator has read payload[i]
     bool itp_pending[2] = {false, false};
@@ -893,6 +901,7 @@ extern "C" void sdrhip_tx_destroy(sdrhip_tx *tx)
         b.in.release(); b.din.release(); b.dout.release(); b.db0.release(); b.out.release();
     }
     if (tx->ev_in) (void)hipEventDestroy(tx->ev_in);
+    if (tx->ev_up) (void)hipEventDestroy(tx->ev_up);
     if (tx->ev_dec) (void)hipEventDestroy(tx->ev_dec);
     for (int i = 0; i < 2; ++i) if (tx->ev_itp[i]) (void)hipEventDestroy(tx->ev_itp[i]);
     delete tx;
@@ -906,6 +915,7 @@ extern "C" int sdrhip_tx_set_pipelined(sdrhip_tx *tx, int on)
     if (on) {
         HIP_TRY(hipSetDevice(tx->ctx->device));
         if (!tx->ev_in) HIP_TRY(hipEventCreateWithFlags(&tx->ev_in, hipEventDisableTiming));
+        if (!tx->ev_up) HIP_TRY(hipEventCreateWithFlags(&tx->ev_up, hipEventDisableTiming));
         if (!tx->ev_dec) HIP_TRY(hipEventCreateWithFlags(&tx->ev_dec, hipEventDisableTiming));
         for (int i = 0; i < 2; ++i) if (!tx->ev_itp[i]) HIP_TRY(hipEventCreateWithFlags(&tx->ev_itp[i], hipEventDisableTiming));
     }
@@ -1042,6 +1052,9 @@ extern "C" int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t
             if (overlap) HIP_TRY(hipStreamSynchronize(s2)); // (the previous decode may still read rxbuf; it ran beside the previous call's interpolator)
             if ((rc = tx->rxbuf.reserve((size_t)S * nframes * fb))) return rc;
             HIP_TRY(hipMemcpy2DAsync(tx->rxbuf.p, nframes * fb, rx, rx_stride_bytes, nframes * fb, S, hipMemcpyHostToDevice, s2));
+            // (pinned caller memory makes this copy truly asynchronous, and it runs on the SECOND stream: the call must not return
+            // before it has read `rx` -- the host-pointer contract is "the buffer is yours again when the call returns")
+            if (overlap) HIP_TRY(hipEventRecord(tx->ev_up, s2));
             drx = tx->rxbuf.as<uint8_t>();
         } else if (overlap) {
             HIP_TRY(hipStreamWaitEvent(s2, tx->ev_in, 0));
@@ -1053,7 +1066,10 @@ extern "C" int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t
         HIP_TRY(hipEventRecord(tx->ev_dec, s2));
         tx->late.have = true; tx->late.n_payload = n_payload; tx->late.pstride = pstride; tx->late.log2interp = tx->log2interp;
         tx->psel ^= 1;
-        if (mem == SDRHIP_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream)); // (the delivered samples; the decode goes on)
+        if (mem == SDRHIP_MEM_HOST) {
+            HIP_TRY(hipStreamSynchronize(c->stream)); // (the delivered samples; the decode goes on)
+            if (overlap) HIP_TRY(hipEventSynchronize(tx->ev_up)); // (... but the caller's rx has been read)
+        }
         return SDRHIP_OK;
     }
 

@@ -121,11 +121,12 @@ def long_golden():
 HEADLINE_META = {"tv_sec": 1, "tv_usec": 0, "center_frequency_khz": 435000, "sample_rate": 625000, "nb_fec": 32}
 
 
-def _headline_stream(ref, orc, n, seed):
-    """one stream of the benchmark: signals.hash_noise(n, seed) -> the REFERENCE's decimate16_cen (EO1 build, one call)
-    -> UDPSinkFEC framing + CM256 128+32 (the oracle's framer with the product's time-stamp rule, and its encoder).
+def _headline_stream(ref, orc, n, seed, x=None):
+    """one stream of the benchmark: signals.hash_noise(n, seed) (or the samples handed in) -> the REFERENCE's decimate16_cen (EO1
+    build, one call) -> UDPSinkFEC framing + CM256 128+32 (the oracle's framer with the product's time-stamp rule, and its encoder).
     -> (sha256 of the decimated stream, sha256 of the finished frames [f][160][512], number of frames)"""
-    x = signals.hash_noise(n, seed)
+    if x is None:
+        x = signals.hash_noise(n, seed)
     y, ss = ref.decimators().decimate(4, 2, 16, x)
     assert ss == 16 and y.shape[0] == n >> 4
     m = HEADLINE_META
@@ -186,6 +187,40 @@ def headline64_golden(procs=8):
             print("headline bank64_25", seed, r[0][:12], r[1][:12], r[2], flush=True)
     out["bank64_25"] = {"seeds": seeds, "log2n": log2n, "dec_sha256": [res[s][0] for s in seeds],
                         "frames_sha256": [res[s][1] for s in seeds], "nframes": [res[s][2] for s in seeds]}
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+
+
+def _ts_stream_job(args):
+    import headline_inputs as hi
+    from oracle_lib import Oracle
+
+    n, seed = args
+    orc = Oracle()
+    x = hi.ts_oracle_samples(orc, n, seed)
+    return seed, hashlib.sha256(x.tobytes()).hexdigest(), _headline_stream(Reference("eo1"), orc, n, seed, x=x)
+
+
+def ts_headline_golden(procs=8):
+    """The headline step on the input every BASELINE config names (VERDICT r5 #3a): bench.py --input testsource -- 8 streams x 2^25
+    samples of the TestSource bank's integer NCO (tests/headline_inputs.py: 10 Msps, -20 dB CW at +100 kHz + 1 kHz x stream), made
+    HERE by the oracle's restatement of that NCO, through the compiled reference's decimate16_cen and the oracle framer + encoder.
+    -> key "ts_bank8" of headline_golden.json (input digests included: the bank's samples themselves are checked too)."""
+    import multiprocessing as mp
+
+    path = os.path.join(HERE, "headline_golden.json")
+    with open(path) as f:
+        out = json.load(f)
+    seeds, log2n = list(range(1000, 1008)), 25
+    res = {}
+    with mp.Pool(procs) as pool:
+        for seed, xs, r in pool.imap_unordered(_ts_stream_job, [(1 << log2n, seed) for seed in seeds]):
+            res[seed] = (xs,) + r
+            print("ts headline", seed, xs[:12], r[0][:12], r[1][:12], r[2], flush=True)
+    import headline_inputs as hi
+    out["ts_bank8"] = {"seeds": seeds, "log2n": log2n, "config": [hi.ts_config_string(s) for s in seeds],
+                       "input_sha256": [res[s][0] for s in seeds], "dec_sha256": [res[s][1] for s in seeds],
+                       "frames_sha256": [res[s][2] for s in seeds], "nframes": [res[s][3] for s in seeds]}
     with open(path, "w") as f:
         json.dump(out, f, indent=0)
 
@@ -286,6 +321,8 @@ if __name__ == "__main__":
         tx_headline_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "headline64":
         headline64_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ts_headline":
+        ts_headline_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "tx_headline":
         tx_headline_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "long":

@@ -11,6 +11,29 @@ TX_KEEP_SEED = 3       # np.random.RandomState seed of the loss patterns
 TX_LOG2_INTERP = 4
 
 
+# ---- the TestSource-shaped input of the headline step (every BASELINE config names TestSource): 10 Msps, a CW carrier 20 dB under
+# full scale at +100 kHz + 1 kHz x (seed mod 1000) (README.md:362's test signal, one offset per stream).  The reference's own
+# generator is a float phasor under -ffast-math (not reproducible): the samples are the integer NCO the
+# library's TestSource bank defines, restated in oracle/sdr_oracle.c (orc_testsource_generate) -- bench.py gets them from the bank
+# on the device, tests/golden/make_golden.py from the oracle on the host, and the digests meet.
+TS_SRATE, TS_POWER_DB = 10000000, 20
+
+
+def ts_offset_hz(seed):
+    return 100000 + 1000 * (seed % 1000)
+
+
+def ts_config_string(seed):
+    """the TestSource::configure message (TestSource.cpp:59-215 keys) of the stream with this seed"""
+    return "srate=%d,dfp=%d,power=%d" % (TS_SRATE, ts_offset_hz(seed), TS_POWER_DB)
+
+
+def ts_oracle_samples(orc, n, seed):
+    """(n, 2) int16: the stream's first n samples by the oracle's NCO (phase 0 at the first sample)"""
+    x, _ = orc.testsource_generate(0, orc.lib.orc_nco_phase_inc(ts_offset_hz(seed), TS_SRATE), orc.lib.orc_nco_amp_q15(TS_POWER_DB), n)
+    return x
+
+
 def tx_keep_sets(nframes_total, seed=TX_KEEP_SEED):
     """(nframes_total, 128) int64: the block indices (ascending) that arrive of every frame: 136 of 160 survive, the collector
     takes the first 128 (SDRdaemonFECBuffer.cpp:143-166)"""

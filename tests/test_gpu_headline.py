@@ -85,6 +85,41 @@ def test_headline_bank_8_x_2p25(ctx):
     _check_frames(view, b)
 
 
+def test_headline_bank_on_testsource_input(ctx):
+    """bench.py's `configs` line on the input every BASELINE config names (VERDICT r5 #3a): the TestSource bank's 8 streams x 2^25
+    samples (tests/headline_inputs.py) generated on the device -- their digests against the oracle NCO's samples --, through the
+    decimator and through the Rx pipe: whole outputs against the digests the compiled reference made of the oracle's samples in
+    the build container (headline_golden.json ts_bank8)"""
+    import torch
+
+    import headline_inputs as hi
+    import sdrdaemon_amd as sd
+
+    b = H["ts_bank8"]
+    S, n = len(b["seeds"]), 1 << b["log2n"]
+    ts = sd.TestSource(ctx, S)
+    for s, seed in enumerate(b["seeds"]):
+        assert hi.ts_config_string(seed) == b["config"][s]
+        assert ts.configure(b["config"][s], s), ts.error()
+    x = ts.read(n).reshape(S, n, 2).contiguous()
+    ctx.synchronize()
+    for s in (0, S - 1):
+        assert _sha(x[s]) == b["input_sha256"][s], ("TestSource samples of stream", s)
+    d = sd.Decimators(ctx, S, sd.HB_EO1)
+    y = torch.empty((S, n >> 4, 2), dtype=torch.int16, device=x.device)
+    d.decimate(4, sd.FC_CEN, 16, x, out=y)
+    ctx.synchronize()
+    assert d.last_plan()["path"] == "mfma"
+    for s in range(S):
+        assert _sha(y[s]) == b["dec_sha256"][s], ("decimated stream", s)
+    del y
+    rx = _rx(ctx, S)
+    view = rx.process_view(x, tv_sec=H["meta"]["tv_sec"], tv_usec=H["meta"]["tv_usec"])
+    ctx.synchronize()
+    assert rx.last_plan()["path"] == "mfma"
+    _check_frames(view, b)
+
+
 def test_headline_bank_ring_depth_3(ctx):
     """the LDS-DMA ring of depth 3 (108 KiB per workgroup: what the decimator runs beside the encoder in overlap mode), on its
     own: the reference digests of the 8 x 2^25 bank"""
@@ -151,11 +186,14 @@ def test_headline_rx_arrangements(ctx, direct, enc):
         ctx.set_option("enc_path", "fft")
 
 
-@pytest.mark.parametrize("log2,S,n,R", [(2, 3, 1 << 21, 8), (3, 2, 1 << 22, 1), (5, 8, 1 << 22, 32), (6, 4, 1 << 23, 16)])
-def test_rx_direct_framing_every_matrix_core_cascade(ctx, log2, S, n, R):
-    """the matrix-core decimator's frame-layout stores for decimate4 .. 64_cen (decimate16: the headline digests): three ragged calls
-    -- the second and third begin inside an open frame, blocks and frames end inside a lane pair's two samples -- against the
-    stream-order arrangement (K2 + fused copy), which the reference chain tests pin; both must have run the matrix-core kernel"""
+@pytest.mark.parametrize("log2,S,n,R,bias", [(2, 3, 1 << 21, 8, 0), (3, 2, 1 << 22, 1, 1), (4, 2, 1 << 23, 32, 0), (5, 8, 1 << 22, 32, 0),
+                                             (6, 4, 1 << 23, 16, 1), (6, 1, 1 << 25, 32, 0)])
+def test_rx_direct_framing_every_matrix_core_cascade(ctx, oracle, log2, S, n, R, bias):
+    """the matrix-core decimator's frame-layout stores (rx_direct) for decimate4 .. 64_cen, both filter flavours: three ragged calls
+    -- the second and third begin inside an open frame, blocks and frames end inside a lane pair's two samples -- against the ORACLE
+    chain on the same calls (decimator -> UDPSinkFEC::write framer -> frame_encode, VERDICT r5 #7: no self-comparison), and against
+    the stream-order arrangement (K2 + fused copy) of the same library; every call must have run the matrix-core kernel"""
+    import numpy as np
     import torch
 
     import sdrdaemon_amd as sd
@@ -163,24 +201,40 @@ def test_rx_direct_framing_every_matrix_core_cascade(ctx, log2, S, n, R):
 
     x = torch.stack([signals.hash_noise_torch(n, 7000 + 13 * log2 + s, "cuda") for s in range(S)])
     cuts = [0, (n // 3) & ~((1 << log2) * 4 - 1), (2 * n // 3 + 4096) & ~((1 << log2) * 4 - 1), n]
+    stamps = [(5, 6), (77, 999999), (1000, 0)]
     ctx.set_option("decim_path", "mfma")
     try:
         outs = []
         for direct in (0, 1):
             ctx.set_option("rx_direct", direct)
-            rx = sd.RxPipe(ctx, S, log2decim=log2, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=R,
+            rx = sd.RxPipe(ctx, S, log2decim=log2, fcpos=sd.FC_CEN, hb_variant=bias, sample_bits=16, nb_fec=R,
                            center_frequency_khz=435000, sample_rate=48000)
             fr = []
-            for a, b in zip(cuts[:-1], cuts[1:]):
-                fr.append(rx.process_view(x[:, a:b], tv_sec=5, tv_usec=6).torch().clone())
+            for (a, b), (ts, tu) in zip(zip(cuts[:-1], cuts[1:]), stamps):
+                fr.append(rx.process_view(x[:, a:b], tv_sec=ts, tv_usec=tu).torch().clone())
                 assert rx.last_plan()["path"] == "mfma", (direct, rx.last_plan())
             outs.append(fr)
         ctx.synchronize()
         for u, v in zip(*outs):
             assert u.shape == v.shape and u.shape[1] > 0 and torch.equal(u, v)
+        got = [f.cpu().numpy() for f in outs[1]]
     finally:
         ctx.set_option("rx_direct", 1)
         ctx.set_option("decim_path", "auto")
+    xh = x.cpu().numpy()
+    for s in range(S):
+        od = oracle.decimators(bias)
+        fr = oracle.framer(nb_fec_blocks=R, sample_rate=48000, sample_bytes=2, sample_bits=16)
+        for i, ((a, b), (ts, tu)) in enumerate(zip(zip(cuts[:-1], cuts[1:]), stamps)):
+            y, ss = od.decimate(log2, sd.FC_CEN, 16, xh[s, a:b])
+            assert ss == 16
+            fr.s.tv_sec, fr.s.tv_usec = ts, tu
+            e = fr.write(y)
+            g = got[i][s]
+            assert g.shape[0] == e.shape[0], (log2, s, i, g.shape, e.shape)
+            for f in range(e.shape[0]):
+                assert np.array_equal(g[f, :128], e[f]), (log2, s, i, f)
+                assert np.array_equal(g[f, 128:], oracle.frame_encode(e[f], R)), (log2, s, i, f)
 
 
 def test_headline_one_stream_2p27(ctx):
@@ -437,12 +491,15 @@ def test_headline_tx_bank_pipelined(ctx, overlap):
         ctx.set_option("tx_overlap", 1)
 
 
-@pytest.mark.parametrize("overlap,device", [(1, False), (1, True), (0, False)], ids=["two-streams-host", "two-streams-device", "one-stream-host"])
+@pytest.mark.parametrize("overlap,device", [(1, False), (1, True), (0, False), (1, "pinned")],
+                         ids=["two-streams-host", "two-streams-device", "one-stream-host", "two-streams-pinned-host"])
 def test_tx_pipelined_many_ragged_calls(ctx, oracle, overlap, device):
     """20 pipelined Tx calls of 1..9 frames on two streams, a different random loss pattern per frame, the interpolation factor
     changed by control messages on the way (a waiting batch keeps the factor it was handed in with), an empty call in the middle
     (delivers like any other): every delivery equals the unpipelined pipe's output of the previous call, and the whole sample
-    stream equals the oracle chain (decode -> interpolators with carried histories)."""
+    stream equals the oracle chain (decode -> interpolators with carried histories).  "pinned": the received frames come from
+    sdrhip_host_alloc memory -- their upload on the second stream is then truly asynchronous -- and are scribbled over the moment
+    the call returns (a host buffer belongs to the caller again when the call returns)."""
     import torch
 
     import sdrdaemon_amd as sd
@@ -461,6 +518,9 @@ def test_tx_pipelined_many_ragged_calls(ctx, oracle, overlap, device):
             allb = np.concatenate([frames[f], oracle.frame_encode(frames[f], R)])
             lost = set(rs.choice(160, 24, replace=False).tolist())
             rxb[s, f] = allb[[i for i in range(160) if i not in lost][:128]]
+    pinned = device == "pinned"
+    device = device is True
+    pin = ctx.host_alloc((S, 9, 128, 512), np.uint8) if pinned else None
     ctx.set_option("tx_overlap", overlap)
     try:
         a = sd.TxPipe(ctx, S, 4)
@@ -471,7 +531,13 @@ def test_tx_pipelined_many_ragged_calls(ctx, oracle, overlap, device):
             batch = rxb[:, pos:pos + c]
             pos += c
             e = a.process(batch) if c else np.zeros((S, 0, 2), np.int16)
-            g = p.process(torch.from_numpy(np.ascontiguousarray(batch)).cuda() if device else batch)
+            if pinned and c:
+                src = pin.reshape(-1)[:S * c * 128 * 512].reshape(S, c, 128, 512)  # (contiguous: passed to the library in place)
+                src[:] = batch
+                g = p.process(src)
+                pin[:] = 0xA5  # the buffer is the caller's again
+            else:
+                g = p.process(torch.from_numpy(np.ascontiguousarray(batch)).cuda() if device else batch)
             g = g.cpu().numpy() if device else g
             if prev is None:
                 assert g.shape == (S, 0, 2)
@@ -495,6 +561,9 @@ def test_tx_pipelined_many_ragged_calls(ctx, oracle, overlap, device):
         assert ctx.lib.sdrhip_tx_set_pipelined(p.h, 0) == 0
     finally:
         ctx.set_option("tx_overlap", 1)
+        if pin is not None:
+            ctx.synchronize()
+            ctx.host_free(pin)
 
 
 @pytest.mark.parametrize("dec_path", ["syndrome", "dense"])

@@ -22,12 +22,18 @@ def regs(text):
 
 
 def check(asm_path):
+    """Linear scan with a merge at basic-block boundaries: a FORWARD branch hands its outstanding loads to its target label (the
+    taken path may have skipped a wait the fall-through path executed), the label continues with the union of both; after a
+    merge the issue order of the union is unknown, so a partial `lgkmcnt(n > 0)` then drops nothing.  A BACKWARD branch (a loop)
+    with a load outstanding is a violation: the scan has passed its target already and cannot follow it."""
     bad, kernels, issues = [], 0, 0
     name, in_asm, pending = None, False, []  # pending: list of (set of registers, line) in issue order, one entry per ds_read
+    merged = False       # pending holds loads of more than one path: their relative order is unknown
+    carried, seen = {}, set()  # label -> loads outstanding at forward branches to it; labels passed so far in this kernel
     for ln, line in enumerate(open(asm_path), 1):
         t = line.strip()
         if re.match(r"^_Z\w+:", t):
-            name, pending, in_asm = t[:-1], [], False
+            name, pending, in_asm, merged, carried, seen = t[:-1], [], False, False, {}, set()
             kernels += 1
             continue
         if t.startswith(";;#ASMSTART"):
@@ -36,9 +42,36 @@ def check(asm_path):
         if t.startswith(";;#ASMEND"):
             in_asm = False
             continue
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            seen.add(m.group(1))
+            extra = carried.pop(m.group(1), [])
+            if extra:
+                have = {l for _, l in pending}
+                add = [e for e in extra if e[1] not in have]
+                if add:
+                    pending = sorted(pending + add, key=lambda e: e[1])
+                    merged = True
+            continue
         if not t or t.startswith(";") or t.startswith("."):
             continue
         op = t.split()[0]
+        if op.startswith("s_cbranch") or op == "s_branch":
+            target = t.split()[-1]
+            if pending:
+                if target in seen:
+                    for r, l in pending:
+                        bad.append((name, ln, t + "  <backward branch with a table load outstanding>", l))
+                else:
+                    carried.setdefault(target, []).extend(pending)
+            if op == "s_branch":
+                pending, merged = [], False  # (what follows is only reachable through its label)
+            continue
+        if op in ("s_setpc_b64", "s_swappc_b64") and pending:
+            for r, l in pending:
+                bad.append((name, ln, t + "  <indirect jump with a table load outstanding>", l))
+            pending = []
+            continue
         if in_asm and op.startswith("ds_read"):
             dst = t.split(",")[0]
             touched = regs(t.split(",", 1)[1]) if "," in t else set()
@@ -52,10 +85,13 @@ def check(asm_path):
             m = re.search(r"lgkmcnt\((\d+)\)", t)
             if m:
                 keep = int(m.group(1))
-                pending = pending[len(pending) - keep:] if keep else []
+                if keep == 0:
+                    pending, merged = [], False
+                elif not merged:
+                    pending = pending[max(0, len(pending) - keep):]  # (keep > len: nothing is dropped)
             continue
         if op == "s_waitcnt" and "lgkmcnt(0)" in t:
-            pending = []  # (the compiler's own full wait covers them too)
+            pending, merged = [], False  # (the compiler's own full wait covers them too)
             continue
         if pending:
             touched = regs(t)
@@ -63,7 +99,7 @@ def check(asm_path):
                 if r & touched:
                     bad.append((name, ln, t, l))
         if op == "s_endpgm":
-            pending = []
+            pending, merged = [], False
     return kernels, issues, bad
 
 
