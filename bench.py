@@ -481,9 +481,11 @@ def drop_in_lines(ctx):
     x = rng.integers(-32768, 32768, (nblk, 2), dtype=np.int16)
     lines = []
 
-    def line(config, us_per_block, nbytes, extra=None):
+    def line(config, us_per_block, nbytes, extra=None, ok=None):
         gbs = nbytes / (us_per_block * 1e-6) / 1e9
-        d = {"config": config, "us_per_block": round(us_per_block, 2), "value": round(nblk / us_per_block, 1), "unit": "Msamples/s (input, host to host)",
+        d = {"config": config, "verified": {"ok": bool(ok), "what": "every byte the host-pointer calls returned for a run of blocks",
+                                            "against": "the device-pointer entry of this library on the same samples (its parity with the oracle / the "
+                                                       "reference digests: the lines above and tests/test_gpu_pipes.py)"}, "us_per_block": round(us_per_block, 2), "value": round(nblk / us_per_block, 1), "unit": "Msamples/s (input, host to host)",
              "roofline": {"bound": "pcie", "achieved": round(gbs, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / PCIE_PEAK_GBS, 4),
                           "peak_source": "PCIe Gen5 x16, 63 GB/s per direction (MI355X_MICROARCH.md, host link)", "traffic": None}}
         if extra:
@@ -499,9 +501,15 @@ def drop_in_lines(ctx):
     for _ in range(K):
         d.decimate(LOG2DECIM, sd.FC_CEN, 16, x)
     us = (time.perf_counter() - t0) / K * 1e6
+    # check: 6 more blocks through host pointers on fresh handles against the same 6 blocks as one device-memory bank call
+    chk = rng.integers(-32768, 32768, (6 * nblk, 2), dtype=np.int16)
+    dh, dd = sd.Decimators(ctx, 1, sd.HB_EO1), sd.Decimators(ctx, 1, sd.HB_EO1)
+    yh = np.concatenate([dh.decimate(LOG2DECIM, sd.FC_CEN, 16, chk[b * nblk:(b + 1) * nblk])[0] for b in range(6)])
+    yd = dd.decimate(LOG2DECIM, sd.FC_CEN, 16, torch.from_numpy(chk).cuda())[0]
+    ctx.synchronize()
     line("drop-in, configs[1] shape: Downsampler::process on one 65 536-sample host block per call (decimate16_cen, synchronous, host pointers)", us,
-         nblk * BYTES_DECIM, {"kernel_path": d.last_plan()["path"]})
-    del d
+         nblk * BYTES_DECIM, {"kernel_path": d.last_plan()["path"]}, ok=np.array_equal(yh.reshape(-1, 2), yd.reshape(-1, 2).cpu().numpy()))
+    del d, dh, dd
     # (b) the Rx pipe on one block per call, synchronous
     rx = sd.RxPipe(ctx, 1, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
                    center_frequency_khz=435000, sample_rate=625000)
@@ -511,9 +519,17 @@ def drop_in_lines(ctx):
     for _ in range(K):
         rx.process(x, 1, 2)
     us = (time.perf_counter() - t0) / K * 1e6
+
+    def pipe():
+        return sd.RxPipe(ctx, 1, log2decim=LOG2DECIM, fcpos=sd.FC_CEN, hb_variant=sd.HB_EO1, sample_bits=16, nb_fec=NB_FEC,
+                         center_frequency_khz=435000, sample_rate=625000)
+
+    rh, rd = pipe(), pipe()
+    fh = np.concatenate([rh.process(chk[b * nblk:(b + 1) * nblk], 1, 2) for b in range(6)])
+    fd = np.concatenate([rd.process(torch.from_numpy(chk[b * nblk:(b + 1) * nblk]).cuda(), 1, 2).cpu().numpy() for b in range(6)])
     line("drop-in, configs[2] shape: sdrhip_rx_process on one 65 536-sample host block per call (decimate16_cen + framing + CM256 128+32, synchronous)", us,
-         nblk * BYTES_CONFIG3)
-    del rx
+         nblk * BYTES_CONFIG3, ok=fh.shape[0] == 1 and np.array_equal(fh, fd))
+    del rx, rh, rd
     # (c) the asynchronous entry: 16 blocks per batch from pageable memory, the collector one batch behind
     blocks, nb = 16, 16 * 16
     src = rng.integers(-32768, 32768, (1, nb * nblk, 2), dtype=np.int16)
@@ -523,29 +539,42 @@ def drop_in_lines(ctx):
     blks = [src[:, b * nblk:(b + 1) * nblk] for b in range(nb)]
     maxf = blocks * nblk // (16129 * 16) + 2
 
-    def run(rounds):
+    def run(rounds, keep=None):
         inflight, frames = 0, 0
+
+        def take():
+            f = rx.collect(wait=True, max_frames=maxf)
+            if keep is not None:
+                keep.append(f[0].copy())
+            return f.shape[1]
+
         for _ in range(rounds):
             for b in range(nb):
                 rx.submit(blks[b], 1, 2)
                 if (b + 1) % blocks == 0:
                     inflight += 1
                     if inflight == 3:
-                        frames += rx.collect(wait=True, max_frames=maxf).shape[1]
+                        frames += take()
                         inflight -= 1
         while inflight:
-            frames += rx.collect(wait=True, max_frames=maxf).shape[1]
+            frames += take()
             inflight -= 1
         return frames
 
-    run(1)
+    first = []
+    run(1, first)
+    # (the first round's frames against the same samples through the device-pointer pipe, batch by batch: same stamps, same frames)
+    rd = pipe()
+    fd = np.concatenate([rd.process(torch.from_numpy(src[:, b * blocks * nblk:(b + 1) * blocks * nblk]).cuda(), 1, 2)[0].cpu().numpy() for b in range(nb // blocks)])
+    ok_async = np.array_equal(np.concatenate(first), fd)
+    del rd
     R = 6
     t0 = time.perf_counter()
     frames = run(R)
     us = (time.perf_counter() - t0) / (R * nb) * 1e6
-    assert abs(frames - R * nb * nblk // (16 * 16129)) <= 1, frames  # (every submitted sample came back framed)
+    ok_async = ok_async and abs(frames - R * nb * nblk // (16 * 16129)) <= 1  # (every submitted sample came back framed)
     line("drop-in, configs[2] shape, asynchronous entry: sdrhip_rx_submit / sdrhip_rx_collect, 65 536-sample host blocks (pageable), %d blocks per "
-         "upload + launch + download, 3 batches in flight" % blocks, us, nblk * BYTES_CONFIG3, {"frames_collected": int(frames)})
+         "upload + launch + download, 3 batches in flight" % blocks, us, nblk * BYTES_CONFIG3, {"frames_collected": int(frames)}, ok=ok_async)
     del rx
     return lines
 
@@ -788,8 +817,9 @@ def main():
                     help="untimed run-in of the same step before the W warm-up steps (the GPU's clocks ramp over the first "
                          "~60 ms of load: with a small W the timed steps would measure that ramp)")
     ap.add_argument("--timer-stride", type=int, default=0,
-                    help="the HIP-event timers of the roofline kernel bracket every N-th step of the timed region (default: 4, and 1 -- "
-                         "every launch -- when --steps < 50, so that the kernel average of a short run rests on all of its launches)")
+                    help="the HIP-event timers of the ROOFLINE kernel (the decimator) bracket every N-th step of the timed region (default: 4, "
+                         "and 1 -- every launch -- when --steps < 50, so that the kernel average of a short run rests on all of its launches); "
+                         "the encoder's timers stay on every 4th step (an event pair costs the stream ~3.5 us: tools/experiments_r06/timer_cost.py)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: leave the per-kernel HIP events out of the timed region (roofline fields become null)")
     ap.add_argument("--no-box-state", action="store_true", help="do not sample socket power / shader clock (amdsmi) beside the timed region")
@@ -875,7 +905,8 @@ def main():
     torch.cuda.synchronize()
     # kernel-class timers (HIP events on the library's stream) over the timed region: every 4th step's launches -- an event pair
     # costs the stream ~2.5 us, four of them per step took 3 % off the step (tools/bench_rx_modes.py times the same step without)
-    ctx.set_option("ktime_stride", args.timer_stride)
+    ctx.set_option("ktime_stride", max(4, args.timer_stride))
+    ctx.set_option("ktime_stride_class", "%d:%d" % (K_DECIMATE, args.timer_stride))
     ctx.kernel_timing(not args.no_kernel_timing)
     if dist is not None:
         dist.barrier()

@@ -229,7 +229,12 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
         else return fail(SDRHIP_EINVAL, "ctx_set_option: dec_path must be syndrome or dense");
     } else if (k == "dec_max_rows" && isnum && num >= 1 && num <= 128) c->opt.dec_max_rows = (int)num;
     else if (k == "dec_strict" && isnum && num <= 1) c->opt.dec_strict = (int)num;
-    else if (k == "ktime_stride" && isnum && num >= 1 && num <= 1024) c->ktime_stride = (int)num;
+    else if (k == "ktime_stride" && isnum && num >= 1 && num <= 1024) { c->ktime_stride = (int)num; for (int i = 0; i < 4; ++i) c->ktime_stride_cls[i] = 0; }
+    else if (k == "ktime_stride_class") { // "<class>:<stride>": this kernel class only (e.g. the roofline kernel on every launch, the others on every 4th)
+        int cls = -1, st = 0;
+        if (sscanf(value, "%d:%d", &cls, &st) != 2 || cls < 0 || cls > 3 || st < 1 || st > 1024) return fail(SDRHIP_EINVAL, "ctx_set_option: ktime_stride_class takes <class 0..3>:<stride 1..1024>");
+        c->ktime_stride_cls[cls] = st;
+    }
     else return fail(SDRHIP_EINVAL, "ctx_set_option: unknown key or malformed value: %s=%s", key, value);
     return SDRHIP_OK;
 }

@@ -173,6 +173,7 @@ struct sdrhip_ctx {
     // per-kernel-class timing with hipEvents on `stream` (sdrhip_ctx_kernel_timing)
     bool ktime_on = false;
     int ktime_stride = 1;                     // kernel-class timers bracket every ktime_stride-th launch of a class (option "ktime_stride")
+    int ktime_stride_cls[4] = {0, 0, 0, 0};   // ... per class when > 0 (option "ktime_stride_class" = "<class>:<stride>"; "ktime_stride" resets them)
     unsigned ktime_seen[4] = {0, 0, 0, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> kev[4];
 };
@@ -192,7 +193,10 @@ struct KTimer {
     {
         if (!c->ktime_on) return;
         // (an event pair around a launch costs the stream ~2.5 us: timing every launch of a two-launch step took 3 % off the step)
-        if (c->ktime_stride > 1 && cls >= 0 && cls < 4 && (c->ktime_seen[cls]++ % (unsigned)c->ktime_stride) != 0) return;
+        if (cls >= 0 && cls < 4) {
+            const int stride = c->ktime_stride_cls[cls] > 0 ? c->ktime_stride_cls[cls] : c->ktime_stride;
+            if (stride > 1 && (c->ktime_seen[cls]++ % (unsigned)stride) != 0) return;
+        }
         hipEvent_t e0 = nullptr;
         if (hipEventCreate(&e0) != hipSuccess) return;
         if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); e1 = nullptr; return; }
