@@ -32,6 +32,7 @@ __device__ __forceinline__ void gf_decode128_fft_wg(const Dec128Args &a, int fr,
             reinterpret_cast<uint4_t *>(pl)[i] = reinterpret_cast<const uint4_t *>(a.plan + (size_t)fr * DEC128_PLAN_BYTES)[i];
     }
     __syncthreads();
+    fec_stagger_sleep(fr, a.stagger, a.stagger_div);
     // (the block half is a template parameter of everything behind this point, like the encoder's: gf_encode128_fft_wave)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wv >> 1) gf_decode128_fft_wave<1>(a, fr, ldsraw, wv & 1);

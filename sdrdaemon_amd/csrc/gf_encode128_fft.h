@@ -363,6 +363,7 @@ __device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi,
 {
     FFT_STAMP(0);
     fft_fill_tables(a, ldsraw);
+    fec_stagger_sleep(fi, a.stagger, a.stagger_div);
     FFT_STAMP(1);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wv >> 1) gf_encode128_fft_wave<1>(a, fi, ldsraw, wv & 1);

@@ -530,6 +530,7 @@ struct Dec128Args {
     size_t payload_frame_bytes;
     uint8_t *block0_out;        // optional [nframes][508]
     int nframes;
+    int stagger, stagger_div;   // staggered start of the workgroups (Enc128Args::stagger)
 };
 constexpr int DEC128_LDS_BYTES = 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4 + DEC128_MAXN * 64 * 4 + DEC128_PLAN_BYTES;
 
@@ -832,6 +833,7 @@ hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *
         Dec128Args k;
         k.rx = rx; k.rx_frame_bytes = rx_frame_bytes; k.plan = d.plan2; k.tab = tab; k.leaf_tables = d.leaf_tables; k.fft_tables = d.fft_tables;
         k.payload_out = payload_out; k.payload_frame_bytes = payload_frame_bytes; k.block0_out = block0_out; k.nframes = nframes;
+        k.stagger = d.stagger; k.stagger_div = d.stagger_div;
         if (d.use_fft && d.fft_tables) hipLaunchKernelGGL(gf_decode128_fft_kernel, dim3(nframes), dim3(GF_NT), 0, stream, k);
         else hipLaunchKernelGGL(gf_decode128_kernel, dim3(2 * nframes), dim3(GF_NT), 0, stream, k);
         e = hipGetLastError();

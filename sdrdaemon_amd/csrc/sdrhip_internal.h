@@ -268,7 +268,21 @@ struct Enc128Args {
     unsigned meta_w[6];
     uint64_t meta_idx0;
     unsigned meta_rate;
+    // staggered start (round 6): the launch is ONE round of resident workgroups that all load first and compute afterwards -- the
+    // memory phase and the VALU phase do not overlap.  Workgroup i sleeps (i / stagger_div) * stagger units of 1024 clocks before
+    // its loads (stagger_div = the number of CUs: the i-th workgroup a CU receives), so that the co-resident workgroups of a CU are
+    // in different phases.  0 = off.
+    int stagger, stagger_div;
 };
+// the sleep in front of a workgroup's loads (Enc128Args::stagger, DecodeBuffers::stagger)
+#if defined(__HIPCC__)
+__device__ __forceinline__ void fec_stagger_sleep(int unit, int stagger, int stagger_div)
+{
+    if (stagger <= 0 || stagger_div <= 0) return;
+    const int n = (unit / stagger_div) * stagger; // (workgroup-uniform)
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+}
+#endif
 // smallest number of recovery blocks the structured 128-original encoder is used for (below: the generic matrix kernel)
 constexpr int ENC128_MIN_ROWS = 13;
 hipError_t launch_gf_encode128(const Enc128Args &a, hipStream_t stream);
@@ -292,6 +306,7 @@ struct DecodeBuffers {
     const uint8_t *leaf_tables; // Karatsuba leaf tables of the 128-original encoder (the syndrome decoder walks the same tree)
     const uint8_t *fft_tables;  // constants of the additive-FFT encoder (gf_decode128_fft.h); NULL or use_fft = 0: the Karatsuba walk
     int use_fft;
+    int stagger, stagger_div;   // staggered start of the FFT decoder's workgroups (see Enc128Args::stagger)
     static size_t bytes(size_t nframes) { return nframes * (128 * 128 + 4 * 128 * sizeof(int16_t) + 2 * sizeof(int32_t) + DECODE_PLAN2_BYTES) + 64; }
 };
 // plan + scatter + apply, all on the stream, no host synchronisation; max_rows = upper bound of the recovery blocks a
