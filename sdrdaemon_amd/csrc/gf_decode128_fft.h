@@ -16,30 +16,145 @@
 constexpr int DEC128_FFT_LDS_BYTES = FFT_TAB_BYTES + 256 * 32 + DEC128_PLAN_BYTES + 2 * FFT_XCH_DWORDS * 4;
 static_assert(DEC128_PLAN_BYTES % 16 == 0 && DEC128_MAXN == 32, "plan record layout");
 
-template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch);
+template <int HF, bool FUSED> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch);
 
-__device__ __forceinline__ void gf_decode128_fft_wg(const Dec128Args &a, int fr, unsigned char *ldsraw)
+// ---- the frame's plan made by the decoder's own workgroup (round 6: FUSED).  gf_decode_plan_kernel (gf_kernels.hip) used to run as a
+// launch of its own in front of this kernel: 16 us per 1024 frames, serial, most of it one workgroup's latency chain.  When no frame
+// can carry more than DEC128_MAXN recovery blocks (the caller's dec_max_rows promise <= 32: the sender's fecblk) everything a frame's
+// record holds is derived HERE, in LDS, by the workgroup that decodes the frame: the classification (where every original lies, which
+// recovery rows came, which originals they restore, N, cm256's DecodeM1 case, the repeated-block and dec_max_rows checks)
+// and the closed-form inverse of the Cauchy block (four logarithm sums per row and column -- LDS atomics over the N x N pairs -- and one
+// table look-up per element: gf_decode_plan_kernel's formulas), all of it in front of the data loads: they need the position map, and
+// anything placed behind their issue waits for them (64 loads per lane in flight: a barrier or a spill reload there drains them first:
+// measured, 87 against 77 us).  Same records, same semantics (SDRdaemonFECBuffer.cpp:143-213 through cm256_decode); a recovery block that
+// comes twice is found by counting (the separate kernel finds it as a singular system: x_i = x_k), an incomplete frame's missing
+// blocks are zeroed by the copy loop itself (Dec128Plan::pad = 1) instead of a fill pass in front.
+struct Dec128Scratch {
+    uint8_t exp[512];          // (exp, then log: the 1 KiB of gf_explog as it is)
+    uint16_t log[256];
+    int cnt[256];              // how often block index b arrived
+    uint8_t x[128], y[128], rpos[128], idx[128];
+    int lpx[DEC128_MAXN], lqx[DEC128_MAXN], lpy[DEC128_MAXN], lqy[DEC128_MAXN];
+    unsigned long long mask[2][3];
+};
+static_assert(sizeof(Dec128Scratch) % 16 == 0, "scratch size");
+constexpr int DEC128_FFT_FUSED_LDS_BYTES = DEC128_FFT_LDS_BYTES + (int)sizeof(Dec128Scratch);
+
+__device__ __forceinline__ void dec128_plan(const Dec128Args &a, int fr, Dec128Plan *pl, Dec128Scratch *s, unsigned char *ldsraw)
 {
-    uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
-    unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES); // all 256 constants: 8 dwords each
-    Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + FFT_TAB_BYTES + 256 * 32);
+    constexpr int K = 128;
     const int tid = threadIdx.x;
+    // the frame's block indices first (the one load the whole chain waits for: 128 header bytes, 512 bytes apart), the tables behind them
+    int b = 0;
+    if (tid < K) b = a.indices ? a.indices[(size_t)fr * K + tid] : a.rx[(size_t)fr * a.rx_frame_bytes + (size_t)tid * 512 + 2];
     {
+        uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
+        unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES);
+        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables);
+        for (int i = tid; i < 2 * FFT_NTAB; i += GF_NT) lt[i] = src[i];
+        for (int i = tid; i < 256 * 2; i += GF_NT) reinterpret_cast<uint4_t *>(tab)[i] = reinterpret_cast<const uint4_t *>(a.tab)[i];
+        if (tid < 64) reinterpret_cast<uint4_t *>(s->exp)[tid] = reinterpret_cast<const uint4_t *>(a.explog)[tid];
+    }
+    s->cnt[tid] = 0;
+    if (tid < 4 * DEC128_MAXN) s->lpx[tid] = 0; // (lpx, lqx, lpy, lqy: consecutive)
+    __syncthreads();
+    if (tid < K) atomicAdd(&s->cnt[b], 1);
+    __syncthreads();
+    const int wv = tid >> 6, ln = tid & 63;
+    const bool is_rec = b >= K;
+    unsigned long long br = 0ull, bm = 0ull;
+    if (tid < K) { // (waves 0 and 1, whole)
+        br = __ballot(is_rec);
+        bm = __ballot(s->cnt[tid] == 0);
+        const unsigned long long bd = __ballot(s->cnt[tid] > 1 || s->cnt[K + tid] > 1); // an original, or a recovery block, more than once
+        if (ln == 0) { s->mask[wv][0] = br; s->mask[wv][1] = bm; s->mask[wv][2] = bd; }
+    }
+    __syncthreads();
+    const int nrec = __popcll(s->mask[0][0]) + __popcll(s->mask[1][0]), nmiss = __popcll(s->mask[0][1]) + __popcll(s->mask[1][1]);
+    const bool dup = (s->mask[0][2] | s->mask[1][2]) != 0ull;
+    const int N = nrec;
+    bool ok = N > 0 && !dup;
+    if (N > a.max_rows) { // more recovery blocks than the caller promised: left as received and COUNTED (gf_decode_plan_kernel)
+        ok = false;
+        if (tid == 0) atomicAdd(a.stats, 1u);
+    }
+    int rrank = 0;
+    if (tid < K) {
+        const unsigned long long below = (1ull << ln) - 1ull;
+        rrank = (wv ? __popcll(s->mask[0][0]) : 0) + __popcll(br & below);
+        const int mrank = (wv ? __popcll(s->mask[0][1]) : 0) + __popcll(bm & below);
+        if (is_rec) { s->x[rrank] = (uint8_t)b; s->rpos[rrank] = (uint8_t)tid; }
+        if (s->cnt[tid] == 0 && mrank < nrec) s->y[mrank] = (uint8_t)tid; // erased originals, ascending
+        pl->inv[tid] = (int16_t)-1;
+        pl->rowidx[tid] = 255;
+    }
+    if (tid == 0) { pl->n = ok ? N : 0; pl->m1 = (ok && N == 1) ? 1 : 0; pl->maxrow = 0; pl->pad = (!ok && nmiss > 0) ? 1 : 0; if (ok && N == 1) pl->minv[0] = 1; }
+    __syncthreads();
+    if (tid < K) {
+        if (b < K) pl->inv[b] = (int16_t)tid; // (a repeated original: any copy)
+        else if (ok) { pl->rowidx[b - K] = (uint8_t)rrank; pl->rpos[rrank] = (uint8_t)tid; atomicMax(&pl->maxrow, b - K); }
+        if (ok && tid < N) {
+            // strict mode: the reference copies back only the descriptors [128 - recoveryCount, 128) (SDRdaemonFECBuffer.cpp:204-211)
+            const bool hole = a.strict && (int)s->rpos[tid] < K - N;
+            pl->ydst[tid] = (uint8_t)(s->y[tid] | (hole ? 0x80 : 0));
+        }
+    }
+    if (!(ok && N >= 2)) { __syncthreads(); return; } // (workgroup-uniform)
+    // Minv[t][i] = PX_i PY_t / ((x_i ^ y_t) QX_i QY_t (y_t ^ 128)), PX_i = prod_k (x_i ^ y_k), PY_t = prod_k (x_k ^ y_t), QX_i = prod_{k != i}
+    // (x_i ^ x_k), QY_t = prod_{k != t} (y_t ^ y_k) (gf_decode_plan_kernel's closed form of the Cauchy inverse): the four logarithm
+    // sums per index as LDS atomics over the N x N pairs -- a pair per thread instead of a serial N-step loop on N threads
+#pragma unroll
+    for (int e = tid; e < DEC128_MAXN * DEC128_MAXN; e += GF_NT) {
+        const int u = e >> 5, v = e & (DEC128_MAXN - 1);
+        if (u < N && v < N) {
+            const int xu = s->x[u], yu = s->y[u], xv = s->x[v], yv = s->y[v];
+            const int lxy = s->log[xu ^ yv];
+            atomicAdd(&s->lpx[u], lxy);
+            atomicAdd(&s->lpy[v], lxy);
+            if (u != v) {
+                atomicAdd(&s->lqx[u], (int)s->log[xu ^ xv]);
+                atomicAdd(&s->lqy[u], (int)s->log[yu ^ yv]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = tid; e < DEC128_MAXN * DEC128_MAXN; e += GF_NT) {
+        const int t = e >> 5, i = e & (DEC128_MAXN - 1);
+        if (t < N && i < N) {
+            const int yt = s->y[t], xi = s->x[i];
+            const int num = s->lpx[i] + s->lpy[t];
+            const int den = s->log[xi ^ yt] + s->lqx[i] + s->lqy[t] + s->log[yt ^ K];
+            pl->minv[i * DEC128_MAXN + (t & 3) * 8 + (t >> 2)] = s->exp[(unsigned)(num + 255 * 80 - den) % 255u]; // (den <= 2 * 254 + 2 * 31 * 254 < 255 * 80)
+        }
+    }
+    __syncthreads();
+}
+
+template <bool FUSED> __device__ __forceinline__ void gf_decode128_fft_wg(const Dec128Args &a, int fr, unsigned char *ldsraw)
+{
+    Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + FFT_TAB_BYTES + 256 * 32);
+    if constexpr (FUSED) {
+        dec128_plan(a, fr, pl, reinterpret_cast<Dec128Scratch *>(ldsraw + DEC128_FFT_LDS_BYTES), ldsraw); // (tables + plan; ends with a barrier)
+    } else {
+        uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
+        unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES); // all 256 constants: 8 dwords each
+        const int tid = threadIdx.x;
         const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables);
         for (int i = tid; i < 2 * FFT_NTAB; i += GF_NT) lt[i] = src[i];
         for (int i = tid; i < 256 * 2; i += GF_NT) reinterpret_cast<uint4_t *>(tab)[i] = reinterpret_cast<const uint4_t *>(a.tab)[i];
         for (int i = tid; i < DEC128_PLAN_BYTES / 16; i += GF_NT)
             reinterpret_cast<uint4_t *>(pl)[i] = reinterpret_cast<const uint4_t *>(a.plan + (size_t)fr * DEC128_PLAN_BYTES)[i];
+        __syncthreads();
     }
-    __syncthreads();
     fec_stagger_sleep(fr, a.stagger, a.stagger_div);
     // (the block half is a template parameter of everything behind this point, like the encoder's: gf_encode128_fft_wave)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wv >> 1) gf_decode128_fft_wave<1>(a, fr, ldsraw, wv & 1);
-    else gf_decode128_fft_wave<0>(a, fr, ldsraw, wv & 1);
+    if (wv >> 1) gf_decode128_fft_wave<1, FUSED>(a, fr, ldsraw, wv & 1);
+    else gf_decode128_fft_wave<0, FUSED>(a, fr, ldsraw, wv & 1);
 }
 
-template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch)
+template <int HF, bool FUSED> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch)
 {
     constexpr int hf = HF;
     unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES); // all 256 constants: 8 dwords each
@@ -48,6 +163,7 @@ template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const De
     const unsigned la = lds_addr(ldsraw);
     unsigned *const xch0 = xall + ch * FFT_XCH_DWORDS;
     const int N = __builtin_amdgcn_readfirstlane(pl->n), m1 = __builtin_amdgcn_readfirstlane(pl->m1);
+    const int zm = FUSED ? __builtin_amdgcn_readfirstlane(pl->pad) : 0; // (fused plan: an incomplete frame's missing blocks are zeroed by the copy loop)
     // descriptors: the frame as it was received (payload of the block at position 0 = byte 4), the payload area (block 1's samples
     // = byte 0).  Offsets with bit 31 set lie beyond their range: such loads return zero, such stores are dropped -- that is how
     // the erased originals read as zero and how lane 63 of the second column half (no column) stores nothing, without a branch.
@@ -61,9 +177,13 @@ template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const De
         const unsigned lc4 = 4u * (live ? col : 126u);
         const unsigned st4 = live ? lc4 : OOB;
         const int b0 = 64 * hf;
+        // the wave's 64 entries of the position map in ONE register (lane L: original b0 + L), handed out with v_readlane: read block
+        // by block from LDS the compiler hoisted all 64 reads to the top -- 64 registers of temporaries under the 64 data loads,
+        // whose first dozen then went to scratch straight from the load (a wait for each in the middle of the burst)
+        const int invv = (int)pl->inv[b0 + (int)lane];
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
-            const int pos = __builtin_amdgcn_readfirstlane((int)pl->inv[b0 + i]); // position of original b0 + i in the received array, -1 = erased
+            const int pos = __builtin_amdgcn_readlane(invv, i); // position of original b0 + i in the received array, -1 = erased
             const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rrx, lc4, (pos < 0 ? 0 : pos & 127) * 512, 0); // (erased: some block that exists)
             d[i] = pos < 0 ? 0u : v;
         }
@@ -74,8 +194,9 @@ template <int HF> __device__ __forceinline__ void gf_decode128_fft_wave(const De
 #pragma unroll
             for (int i = decltype(first)::value; i < decltype(last)::value; ++i) {
                 const int j = b0 + i; // (uniform)
-                const int pos = __builtin_amdgcn_readfirstlane((int)pl->inv[j]);
-                if (pos < 0) continue; // (uniform; nothing is defined in here: no join of register values)
+                const int pos = __builtin_amdgcn_readlane(invv, i);
+                if (pos < 0 && !zm) continue; // (uniform; nothing is defined in here: no join of register values)
+                // (pos < 0 with zm: the block never arrived and nothing will restore it -- d[i] is zero -- initDecodeSlot's zero fill, .cpp:109)
                 if (i == 0 && hf == 0) {
                     if (a.block0_out && live) reinterpret_cast<unsigned *>(a.block0_out + (size_t)fr * 508)[col] = d[0];
                 } else {

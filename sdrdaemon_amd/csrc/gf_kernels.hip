@@ -531,6 +531,11 @@ struct Dec128Args {
     uint8_t *block0_out;        // optional [nframes][508]
     int nframes;
     int stagger, stagger_div;   // staggered start of the workgroups (Enc128Args::stagger)
+    // fused plan (gf_decode128_fft_plan_kernel: the workgroup derives its frame's record itself, no gf_decode_plan_kernel launch)
+    const uint8_t *indices;     // optional [nframes][128] block indices (device); NULL = the headers' blockIndex
+    const uint8_t *explog;      // exp[512] + log[256] (uint16) of GF(256)
+    int max_rows, strict;       // DecPlanArgs::max_rows (<= DEC128_MAXN here), ::strict
+    unsigned *stats;            // DecPlanArgs::stats
 };
 constexpr int DEC128_LDS_BYTES = 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4 + DEC128_MAXN * 64 * 4 + DEC128_PLAN_BYTES;
 
@@ -741,7 +746,13 @@ __global__ __launch_bounds__(GF_NT, 4) void gf_decode128_fft_kernel(Dec128Args a
         }
         return;
     }
-    gf_decode128_fft_wg(a, fr, ldsraw);
+    gf_decode128_fft_wg<false>(a, fr, ldsraw);
+}
+// ... with the frame's plan derived by the workgroup itself (dec_max_rows <= 32: no frame can need the Karatsuba walk or the dense kernel)
+__global__ __launch_bounds__(GF_NT, 4) void gf_decode128_fft_plan_kernel(Dec128Args a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ldsraw[DEC128_FFT_FUSED_LDS_BYTES];
+    gf_decode128_fft_wg<true>(a, (int)blockIdx.x, ldsraw);
 }
 
 } // namespace
@@ -818,6 +829,16 @@ hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *
     if (nframes <= 0) return hipSuccess;
     if (max_rows < 1) max_rows = 1;
     if (max_rows > 128) max_rows = 128;
+    if (d.plan2 && d.use_fft && d.fft_tables && d.fused_plan && max_rows <= DEC128_MAXN) {
+        // one launch: every workgroup plans its own frame (gf_decode128_fft.h: dec128_plan_front / _back)
+        Dec128Args k;
+        k.rx = rx; k.rx_frame_bytes = rx_frame_bytes; k.plan = nullptr; k.tab = tab; k.leaf_tables = d.leaf_tables; k.fft_tables = d.fft_tables;
+        k.payload_out = payload_out; k.payload_frame_bytes = payload_frame_bytes; k.block0_out = block0_out; k.nframes = nframes;
+        k.stagger = d.stagger; k.stagger_div = d.stagger_div;
+        k.indices = indices_dev; k.explog = explog; k.max_rows = max_rows; k.strict = strict; k.stats = stats;
+        hipLaunchKernelGGL(gf_decode128_fft_plan_kernel, dim3(nframes), dim3(GF_NT), 0, stream, k);
+        return hipGetLastError();
+    }
     DecPlanArgs p;
     p.max_rows = max_rows; p.stats = stats; p.strict = strict;
     p.rx = rx; p.rx_frame_bytes = rx_frame_bytes; p.indices = indices_dev; p.explog = explog;
@@ -834,6 +855,7 @@ hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *
         k.rx = rx; k.rx_frame_bytes = rx_frame_bytes; k.plan = d.plan2; k.tab = tab; k.leaf_tables = d.leaf_tables; k.fft_tables = d.fft_tables;
         k.payload_out = payload_out; k.payload_frame_bytes = payload_frame_bytes; k.block0_out = block0_out; k.nframes = nframes;
         k.stagger = d.stagger; k.stagger_div = d.stagger_div;
+        k.indices = nullptr; k.explog = nullptr; k.max_rows = max_rows; k.strict = strict; k.stats = stats;
         if (d.use_fft && d.fft_tables) hipLaunchKernelGGL(gf_decode128_fft_kernel, dim3(nframes), dim3(GF_NT), 0, stream, k);
         else hipLaunchKernelGGL(gf_decode128_kernel, dim3(2 * nframes), dim3(GF_NT), 0, stream, k);
         e = hipGetLastError();

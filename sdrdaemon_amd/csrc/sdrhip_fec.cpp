@@ -22,7 +22,7 @@ int fec_encode128_launch(sdrhip_ctx *c, const Enc128Args &k, hipStream_t on)
     {
         KTimer kt(c, SDRHIP_K_FEC_ENCODE, on);
         Enc128Args ks = k;
-        ks.stagger = c->opt.fec_stagger; ks.stagger_div = c->n_cu;
+        ks.stagger = c->opt.fec_stagger; ks.stagger_div = c->opt.fec_stagger_mod ? -c->opt.fec_stagger_mod : c->n_cu;
         e = launch_gf_encode128(ks, on ? on : c->stream);
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec encode launch: %s", hipGetErrorString(e));
@@ -44,7 +44,7 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
         k.rows = nb_fec; k.nframes = (int)nframes;
         k.frame_list = frame_list_dev; k.nlist = frame_list_dev ? ngroups * GF_FRAMES_PER_GROUP : (int)nframes;
         if (lin) { k.lin = lin->lin; k.lin_stride = lin->stride; k.lin_cap = lin->cap; k.lin_first = lin->first; k.lin_pending = lin->pending; }
-        k.stagger = c->opt.fec_stagger; k.stagger_div = c->n_cu;
+        k.stagger = c->opt.fec_stagger; k.stagger_div = c->opt.fec_stagger_mod ? -c->opt.fec_stagger_mod : c->n_cu;
         {
             KTimer kt(c, SDRHIP_K_FEC_ENCODE);
             e = launch_gf_encode128(k, c->stream);
@@ -104,7 +104,8 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
     d.plan2 = c->opt.dec_syndrome ? base : nullptr;
     d.leaf_tables = c->enc_leaves;
     d.fft_tables = c->enc_fft; d.use_fft = c->opt.enc_fft;
-    d.stagger = c->opt.fec_stagger; d.stagger_div = c->n_cu;
+    d.stagger = c->opt.fec_stagger; d.stagger_div = c->opt.fec_stagger_mod ? -c->opt.fec_stagger_mod : c->n_cu;
+    d.fused_plan = c->opt.dec_fused_plan;
     const uint8_t *idx_dev = nullptr;
     if (indices) {
         const size_t nb = nframes * (size_t)SDRHIP_NB_ORIGINAL;

@@ -132,7 +132,9 @@ struct CtxOptions {
     int tx_overlap = 1;                    // pipelined Tx pipe: 1 = decode of this batch on the second stream beside the interpolator of the previous one, 0 = one stream
     int enc_fft = 1;                       // structured 128-original encoder, rows <= 32: additive FFT (1) or the Karatsuba XOR-convolution walk (0)
     int enc_min_rows = 1;                  // ... the FFT from this many recovery blocks on (the generic matrix kernel below)
+    int fec_stagger_mod = 0;               // 0: phase = resident round (workgroup / CUs); m > 0: phase = workgroup mod m (experiment)
     int fec_stagger = 0;                   // staggered start of the FFT encoder's / decoder's workgroups, units of 1024 clocks per resident round (0 = off)
+    int dec_fused_plan = 1;                // batched decode with dec_max_rows <= 32 on the FFT decoder: the plan is made inside the decoder's launch (0: gf_decode_plan_kernel in front)
     int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)
     int dec_strict = 0;                    // batched decode delivers only what the reference's copy-back loop delivers (SDRdaemonFECBuffer.cpp:204-211)
     int dec_max_rows = 128;                // upper bound of the recovery blocks a received frame can have used (the sender's fecblk)

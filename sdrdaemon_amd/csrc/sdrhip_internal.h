@@ -278,8 +278,9 @@ struct Enc128Args {
 #if defined(__HIPCC__)
 __device__ __forceinline__ void fec_stagger_sleep(int unit, int stagger, int stagger_div)
 {
-    if (stagger <= 0 || stagger_div <= 0) return;
-    const int n = (unit / stagger_div) * stagger; // (workgroup-uniform)
+    if (stagger <= 0 || stagger_div == 0) return;
+    // stagger_div > 0: phase = the resident round (unit / CUs); < 0: phase = unit mod -stagger_div (consecutive workgroups on one CU)
+    const int n = (stagger_div > 0 ? unit / stagger_div : unit % -stagger_div) * stagger; // (workgroup-uniform)
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
 }
 #endif
@@ -307,6 +308,7 @@ struct DecodeBuffers {
     const uint8_t *fft_tables;  // constants of the additive-FFT encoder (gf_decode128_fft.h); NULL or use_fft = 0: the Karatsuba walk
     int use_fft;
     int stagger, stagger_div;   // staggered start of the FFT decoder's workgroups (see Enc128Args::stagger)
+    int fused_plan;             // 1: frames that can carry at most DEC128_MAXN recovery blocks are planned by the decoder's own workgroups (one launch)
     static size_t bytes(size_t nframes) { return nframes * (128 * 128 + 4 * 128 * sizeof(int16_t) + 2 * sizeof(int32_t) + DECODE_PLAN2_BYTES) + 64; }
 };
 // plan + scatter + apply, all on the stream, no host synchronisation; max_rows = upper bound of the recovery blocks a
