@@ -193,6 +193,7 @@ private:
     {
         std::vector<unsigned long> seqs; // sequence numbers (position in the hand-out order) of the frames that go to the GPU
         std::vector<unsigned char> rxb;
+        int maxrec = 0; // most recovery blocks any frame of this batch holds: the collector counted them, so this is no guess
         for (std::deque<Collect>::iterator it = m_closed.begin(); it != m_closed.end(); ++it) {
             m_ready.push_back(Ready());
             Ready &r = m_ready.back();
@@ -208,6 +209,7 @@ private:
                     std::cerr << "SDRdaemonFECBuffer::getSlotData: incomplete frame: m_blockCount: " << it->count
                               << " m_recoveryCount: " << it->nrec << std::endl;
             } else if (it->nrec > 0 && m_tx) {
+                if (it->nrec > maxrec) maxrec = it->nrec;
                 seqs.push_back(seq);
                 rxb.insert(rxb.end(), it->rx.begin(), it->rx.end());
             }
@@ -215,6 +217,13 @@ private:
         m_closed.clear();
         if (seqs.empty()) return;
         while ((int)m_batches.size() >= MAXINFLIGHT) collectBatch(); // (the ring is full: the oldest batch first)
+        {
+            // tell the library how many recovery blocks a frame of this batch can hold (the option "dec_max_rows", sdrhip.h): with
+            // <= 32 -- every sender up to fecblk 32 -- the decoder plans each frame inside its own launch (one kernel instead of two)
+            char v[16];
+            std::snprintf(v, sizeof(v), "%d", maxrec < 1 ? 1 : maxrec);
+            (void)sdrhip_ctx_set_option(m_ctx, "dec_max_rows", v);
+        }
         if (sdrhip_tx_submit(m_tx, &rxb[0], 0, seqs.size(), 0) != SDRHIP_OK) {
             std::cerr << "SDRdaemonFECBuffer::writeAndRead: CM256 decode error (" << sdrhip_last_error() << ")" << std::endl;
             return; // the frames keep what was received

@@ -2,7 +2,7 @@
 """Is a kernel's launch time a function of the DUTY CYCLE it runs at?  (GPU box.)  The same launches back to back, and with the
 host idling between them (synchronise + sleep): a kernel that runs at the board's power cap gets faster when the chip rests in
 between -- its clock floats with the average power -- while a kernel bound by its own critical path does not care.
-usage: python tools/power_duty.py [decim|interp|enc]..."""
+usage: python tools/power_duty.py [decim|decim32|decim64|one27|interp|interp2|enc]..."""
 import os
 import sys
 import time
@@ -55,6 +55,28 @@ if "decim" in what:
     d = sd.Decimators(ctx, S)
     run("decimate16_cen (K1m)", lambda: d.decimate(4, 2, 16, x, out=out), K_DECIMATE)
     del x, out
+for L in (5, 6):  # decimate32 / 64_cen on the matrix cores (at the same power wall as decimate16?)
+    if "decim%d" % (1 << L) in what:
+        S, n = 8, 1 << 25
+        x = torch.randint(-32768, 32768, (S, n, 2), generator=g, device=dev, dtype=torch.int16)
+        out = torch.empty((S, n >> L, 2), dtype=torch.int16, device=dev)
+        d = sd.Decimators(ctx, S)
+        run("decimate%d_cen (K1m)" % (1 << L), lambda: d.decimate(L, 2, 16, x, out=out), K_DECIMATE)
+        assert d.last_plan()["path"] == "mfma"
+        del x, out, d
+if "one27" in what:  # configs[2] literally: one stream of 2^27
+    x = torch.randint(-32768, 32768, (1, 1 << 27, 2), generator=g, device=dev, dtype=torch.int16)
+    out = torch.empty((1, 1 << 23, 2), dtype=torch.int16, device=dev)
+    d = sd.Decimators(ctx, 1)
+    run("decimate16_cen, 1 x 2^27 (K1m)", lambda: d.decimate(4, 2, 16, x, out=out), K_DECIMATE)
+    del x, out, d
+if "interp2" in what:  # interpolate2_cen: a single stage, the K5 kernel
+    S, n_out = 8, 1 << 25
+    x = torch.randint(-32768, 32768, (S, n_out >> 1, 2), generator=g, device=dev, dtype=torch.int16)
+    out = torch.empty((S, n_out, 2), dtype=torch.int16, device=dev)
+    u = sd.Interpolators(ctx, S)
+    run("interpolate2_cen (K5)", lambda: u.interpolate(1, x, out=out), K_INTERPOLATE)
+    del x, out, u
 if "interp" in what:
     S, n_out = 8, 1 << 25
     x = torch.randint(-32768, 32768, (S, n_out >> 4, 2), generator=g, device=dev, dtype=torch.int16)
