@@ -72,16 +72,22 @@ void sdrhip_ctx_destroy(sdrhip_ctx *ctx);
 int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
 /* Kernel-path knobs for tests and tools (production code never needs them).  The defaults are read from the environment
  * ONCE, when the context is created (SDRHIP_DECIM_PATH, SDRHIP_MFMA_SPAN, SDRHIP_MFMA_MIN, SDRHIP_INTERP_PATH,
- * SDRHIP_INTERP_SPAN, SDRHIP_RX_FUSED, SDRHIP_RX_DIRECT, SDRHIP_ENC_PATH, SDRHIP_ENC_MIN_ROWS, SDRHIP_MFMA_RING, SDRHIP_TX_OVERLAP); keys:
+ * SDRHIP_INTERP_SPAN, SDRHIP_RX_FUSED, SDRHIP_RX_DIRECT, SDRHIP_RX_WINDOW, SDRHIP_ENC_PATH, SDRHIP_ENC_MIN_ROWS, SDRHIP_MFMA_RING,
+ * SDRHIP_TX_OVERLAP, SDRHIP_DEC_PATH, SDRHIP_DEC_PLAN, SDRHIP_FEC_STAGGER[_MOD]); keys:
  * "decim_path" = auto | valu | mfma, "mfma_span" / "mfma_min" / "interp_span" = decimal sample counts, "interp_path" = auto | wave | valu
  * (wave = K5w, the default from interpolate4 up; valu = K5), "rx_fused" = 0 | 1 | 2 | overlap (pipelined Rx: where the deferred encode
  * runs), "rx_direct" = 1 | 0 (Rx pipe on the matrix-core decimator: frame-layout stores, the default, or stream order + framing pass),
  * "enc_path" = fft | karatsuba (CM256 128 + R encoder and the batched decoder's walk: additive FFT for R <= 32, the default, or the
  * Karatsuba XOR-convolution walk), "enc_min_rows" = 1..32 (fewest recovery blocks the FFT encoder serves; below: the generic matrix
- * kernel), "mfma_ring" = 4 | 3, "tx_overlap" = 1 | 0 (pipelined Tx: decode on the second stream), "dec_path" = syndrome | dense.  Every
- * setting computes the same bytes.  One knob is a promise, not a path: "dec_max_rows" = 1..128 (default 128), the most recovery
- * blocks a received frame can carry (the sender's fecblk, known from the meta block); <= 32 spares the batched decoder the
- * launches of its fallback kernel.  The promise is checked on the device: a frame that carries MORE recovery blocks than
+ * kernel), "mfma_ring" = 4 | 3, "tx_overlap" = 1 | 0 (pipelined Tx: decode on the second stream), "dec_path" = syndrome | dense, "dec_plan" =
+ * fused | kernel (batched decode with dec_max_rows <= 32 on the FFT decoder: each frame's plan is made by the decoder's own
+ * workgroup, the default, or by the planning kernel in a launch of its own), "rx_window" = 0 | 1..8 (frame window of the Rx pipe in
+ * calls; 0 = the default: 2, pipelined pipes 4), "fec_stagger" / "fec_stagger_mod" (experiment: staggered start of the FFT encoder's /
+ * decoder's workgroups, default off), "ktime_stride" = 1..1024 / "ktime_stride_class" = "<class>:<stride>" (the kernel-class timers
+ * of sdrhip_ctx_kernel_timing bracket every n-th launch, of all classes / of one).  Every setting computes the same bytes.  One knob is a promise, not a path: "dec_max_rows" = 1..128 (default 128), the most recovery
+ * blocks a received frame can carry (the sender's fecblk, known from the meta block; a collector that counted the recovery blocks
+ * of a batch -- adapters/UDPSourceFEC.h -- passes that count); <= 32 makes the batched decode ONE launch (the plan inside the
+ * decoder, no fallback kernel).  The promise is checked on the device: a frame that carries MORE recovery blocks than
  * dec_max_rows is left as received (like an undecodable frame: missing originals read zero) and counted, see
  * sdrhip_ctx_get_counter("dec_rows_exceeded").  One knob selects behaviour: "dec_strict" = 0 | 1 (default 0).  The reference copies
  * back only the descriptors [128 - recoveryCount, 128) after cm256_decode (SDRdaemonFECBuffer.cpp:204-211: it relies on the
