@@ -16,7 +16,7 @@
 constexpr int DEC128_FFT_LDS_BYTES = FFT_TAB_BYTES + 256 * 32 + DEC128_PLAN_BYTES + 2 * FFT_XCH_DWORDS * 4;
 static_assert(DEC128_PLAN_BYTES % 16 == 0 && DEC128_MAXN == 32, "plan record layout");
 
-template <int HF, bool FUSED> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch);
+template <int HF, bool FUSED, bool NOCOPY> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch);
 
 // ---- the frame's plan made by the decoder's own workgroup (round 6: FUSED).  gf_decode_plan_kernel (gf_kernels.hip) used to run as a
 // launch of its own in front of this kernel: 16 us per 1024 frames, serial, most of it one workgroup's latency chain.  When no frame
@@ -78,11 +78,12 @@ __device__ __forceinline__ void dec128_plan(const Dec128Args &a, int fr, Dec128P
         ok = false;
         if (tid == 0) atomicAdd(a.stats, 1u);
     }
-    int rrank = 0;
+    int rrank = 0, mrank_of_tid = K;
     if (tid < K) {
         const unsigned long long below = (1ull << ln) - 1ull;
         rrank = (wv ? __popcll(s->mask[0][0]) : 0) + __popcll(br & below);
         const int mrank = (wv ? __popcll(s->mask[0][1]) : 0) + __popcll(bm & below);
+        if (s->cnt[tid] == 0) mrank_of_tid = mrank; // original `tid` is the mrank-th missing one (ascending): row mrank of the inverse restores it
         if (is_rec) { s->x[rrank] = (uint8_t)b; s->rpos[rrank] = (uint8_t)tid; }
         if (s->cnt[tid] == 0 && mrank < nrec) s->y[mrank] = (uint8_t)tid; // erased originals, ascending
         pl->inv[tid] = (int16_t)-1;
@@ -97,6 +98,21 @@ __device__ __forceinline__ void dec128_plan(const Dec128Args &a, int fr, Dec128P
             // strict mode: the reference copies back only the descriptors [128 - recoveryCount, 128) (SDRdaemonFECBuffer.cpp:204-211)
             const bool hole = a.strict && (int)s->rpos[tid] < K - N;
             pl->ydst[tid] = (uint8_t)(s->y[tid] | (hole ? 0x80 : 0));
+        }
+    }
+    if (a.srcmap) {
+        // no-copy mode (the Tx pipe on K5w): nothing is copied; the interpolator finds original `tid` of this frame through the map --
+        // where it arrived (super block slot of the received frames), the slot this launch restores it into (row mrank of the
+        // inverse -> slot mrank of the frame's restored blocks), or the all-zero slot behind the last frame's (it never came and
+        // cannot be restored: initDecodeSlot's zero fill, SDRdaemonFECBuffer.cpp:109)
+        __syncthreads(); // (pl->inv is complete)
+        if (tid >= 1 && tid < K) {
+            const int pos = pl->inv[tid];
+            unsigned code;
+            if (pos >= 0) code = (unsigned)fr * 128u + (unsigned)pos;
+            else if (ok && mrank_of_tid < N) code = 0x80000000u | ((unsigned)fr * (unsigned)a.restored_rows + (unsigned)mrank_of_tid);
+            else code = 0x80000000u | ((unsigned)a.nframes * (unsigned)a.restored_rows);
+            a.srcmap[(size_t)fr * 128u + tid] = code;
         }
     }
     if (!(ok && N >= 2)) { __syncthreads(); return; } // (workgroup-uniform)
@@ -131,7 +147,7 @@ __device__ __forceinline__ void dec128_plan(const Dec128Args &a, int fr, Dec128P
     __syncthreads();
 }
 
-template <bool FUSED> __device__ __forceinline__ void gf_decode128_fft_wg(const Dec128Args &a, int fr, unsigned char *ldsraw)
+template <bool FUSED, bool NOCOPY = false> __device__ __forceinline__ void gf_decode128_fft_wg(const Dec128Args &a, int fr, unsigned char *ldsraw)
 {
     Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + FFT_TAB_BYTES + 256 * 32);
     if constexpr (FUSED) {
@@ -150,11 +166,11 @@ template <bool FUSED> __device__ __forceinline__ void gf_decode128_fft_wg(const 
     fec_stagger_sleep(fr, a.stagger, a.stagger_div);
     // (the block half is a template parameter of everything behind this point, like the encoder's: gf_encode128_fft_wave)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wv >> 1) gf_decode128_fft_wave<1, FUSED>(a, fr, ldsraw, wv & 1);
-    else gf_decode128_fft_wave<0, FUSED>(a, fr, ldsraw, wv & 1);
+    if (wv >> 1) gf_decode128_fft_wave<1, FUSED, NOCOPY>(a, fr, ldsraw, wv & 1);
+    else gf_decode128_fft_wave<0, FUSED, NOCOPY>(a, fr, ldsraw, wv & 1);
 }
 
-template <int HF, bool FUSED> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch)
+template <int HF, bool FUSED, bool NOCOPY> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch)
 {
     constexpr int hf = HF;
     unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES); // all 256 constants: 8 dwords each
@@ -164,11 +180,17 @@ template <int HF, bool FUSED> __device__ __forceinline__ void gf_decode128_fft_w
     unsigned *const xch0 = xall + ch * FFT_XCH_DWORDS;
     const int N = __builtin_amdgcn_readfirstlane(pl->n), m1 = __builtin_amdgcn_readfirstlane(pl->m1);
     const int zm = FUSED ? __builtin_amdgcn_readfirstlane(pl->pad) : 0; // (fused plan: an incomplete frame's missing blocks are zeroed by the copy loop)
+    // no-copy mode (fused plan only, Dec128Args::srcmap): the received originals stay where they are, the restored ones go to the
+    // frame's slots of a.restored (row t -> slot t); block 0 (the meta block) still goes to block0_out when the caller wants it
+    // (a template parameter: as a run-time flag the two variants' stores met in joins the register allocator answered with 74 spills)
+    static_assert(!NOCOPY || FUSED, "no-copy mode needs the fused plan (it writes the map)");
+    constexpr bool nocopy = NOCOPY;
     // descriptors: the frame as it was received (payload of the block at position 0 = byte 4), the payload area (block 1's samples
     // = byte 0).  Offsets with bit 31 set lie beyond their range: such loads return zero, such stores are dropped -- that is how
     // the erased originals read as zero and how lane 63 of the second column half (no column) stores nothing, without a branch.
     const __amdgpu_buffer_rsrc_t rrx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.rx) + (size_t)fr * a.rx_frame_bytes + 4, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rpay = __builtin_amdgcn_make_buffer_rsrc(a.payload_out + (size_t)fr * a.payload_frame_bytes, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpay = __builtin_amdgcn_make_buffer_rsrc(nocopy ? a.restored + (size_t)fr * (size_t)a.restored_rows * 508u : a.payload_out + (size_t)fr * a.payload_frame_bytes,
+                                                                          0, 0x7fffffff, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     unsigned d[64], e[16];
     {
@@ -177,6 +199,13 @@ template <int HF, bool FUSED> __device__ __forceinline__ void gf_decode128_fft_w
         const unsigned lc4 = 4u * (live ? col : 126u);
         const unsigned st4 = live ? lc4 : OOB;
         const int b0 = 64 * hf;
+        if (NOCOPY && N == 0) { // (workgroup-uniform, in front of every barrier) nothing to restore, nothing to copy -- but the meta block
+            if (hf == 0 && a.block0_out && live) {
+                const int p0 = __builtin_amdgcn_readfirstlane((int)pl->inv[0]);
+                reinterpret_cast<unsigned *>(a.block0_out + (size_t)fr * 508)[col] = p0 < 0 ? 0u : __builtin_amdgcn_raw_buffer_load_b32(rrx, lc4, (p0 & 127) * 512, 0);
+            }
+            return;
+        }
         // the wave's 64 entries of the position map in ONE register (lane L: original b0 + L), handed out with v_readlane: read block
         // by block from LDS the compiler hoisted all 64 reads to the top -- 64 registers of temporaries under the 64 data loads,
         // whose first dozen then went to scratch straight from the load (a wait for each in the middle of the burst)
@@ -195,6 +224,7 @@ template <int HF, bool FUSED> __device__ __forceinline__ void gf_decode128_fft_w
             for (int i = decltype(first)::value; i < decltype(last)::value; ++i) {
                 const int j = b0 + i; // (uniform)
                 const int pos = __builtin_amdgcn_readlane(invv, i);
+                if constexpr (NOCOPY) { if (!(i == 0 && hf == 0)) continue; } // (no-copy mode: only the meta block travels)
                 if (pos < 0 && !zm) continue; // (uniform; nothing is defined in here: no join of register values)
                 // (pos < 0 with zm: the block never arrived and nothing will restore it -- d[i] is zero -- initDecodeSlot's zero fill, .cpp:109)
                 if (i == 0 && hf == 0) {
@@ -219,7 +249,7 @@ template <int HF, bool FUSED> __device__ __forceinline__ void gf_decode128_fft_w
                 const unsigned rec = __builtin_amdgcn_raw_buffer_load_b32(rrx, lc4, rp * 512, 0);
                 const int yy = __builtin_amdgcn_readfirstlane((int)pl->ydst[0]), y = yy & 0x7f;
                 const unsigned val = (yy & 0x80) ? 0u : (P ^ rec); // (strict mode: a block the reference's copy-back would miss stays a hole)
-                if (y >= 1) __builtin_amdgcn_raw_buffer_store_b32(val, rpay, st4, (y - 1) * 508, 0);
+                if (y >= 1) __builtin_amdgcn_raw_buffer_store_b32(val, rpay, st4, nocopy ? 0 : (y - 1) * 508, 0);
                 else if (a.block0_out && live) reinterpret_cast<unsigned *>(a.block0_out + (size_t)fr * 508)[col] = val;
             }
             return;
@@ -328,7 +358,7 @@ template <int HF, bool FUSED> __device__ __forceinline__ void gf_decode128_fft_w
             if (u < (g ? nm1 : nm0)) {
                 const int yy = __builtin_amdgcn_readfirstlane((int)pl->ydst[hf + 2 * g + 4 * u]), y = yy & 0x7f;
                 const unsigned val = (yy & 0x80) ? 0u : acc[g][u]; // (strict mode: a block the reference's copy-back would miss stays a hole)
-                if (y >= 1) __builtin_amdgcn_raw_buffer_store_b32(val, rpay, st4, (y - 1) * 508, 0);
+                if (y >= 1) __builtin_amdgcn_raw_buffer_store_b32(val, rpay, st4, nocopy ? (hf + 2 * g + 4 * u) * 508 : (y - 1) * 508, 0);
                 else if (a.block0_out && col < 127u) reinterpret_cast<unsigned *>(a.block0_out + (size_t)fr * 508)[col] = val;
             }
         }

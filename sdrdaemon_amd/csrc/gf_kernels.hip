@@ -536,6 +536,10 @@ struct Dec128Args {
     const uint8_t *explog;      // exp[512] + log[256] (uint16) of GF(256)
     int max_rows, strict;       // DecPlanArgs::max_rows (<= DEC128_MAXN here), ::strict
     unsigned *stats;            // DecPlanArgs::stats
+    // no-copy mode (fused plan only; the Tx pipe in front of K5w's gather variant, InterpArgs::gmap): srcmap != NULL
+    unsigned *srcmap;           // [nframes][128]: where original j of frame f lies (gf_decode128_fft.h: dec128_plan)
+    uint8_t *restored;          // [nframes * restored_rows + 1] slots of 508 bytes: row t of frame f -> slot f * restored_rows + t; the last slot stays zero
+    int restored_rows;
 };
 constexpr int DEC128_LDS_BYTES = 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4 + DEC128_MAXN * 64 * 4 + DEC128_PLAN_BYTES;
 
@@ -749,10 +753,10 @@ __global__ __launch_bounds__(GF_NT, 4) void gf_decode128_fft_kernel(Dec128Args a
     gf_decode128_fft_wg<false>(a, fr, ldsraw);
 }
 // ... with the frame's plan derived by the workgroup itself (dec_max_rows <= 32: no frame can need the Karatsuba walk or the dense kernel)
-__global__ __launch_bounds__(GF_NT, 4) void gf_decode128_fft_plan_kernel(Dec128Args a)
+template <bool NOCOPY> __global__ __launch_bounds__(GF_NT, 4) void gf_decode128_fft_plan_kernel(Dec128Args a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char ldsraw[DEC128_FFT_FUSED_LDS_BYTES];
-    gf_decode128_fft_wg<true>(a, (int)blockIdx.x, ldsraw);
+    gf_decode128_fft_wg<true, NOCOPY>(a, (int)blockIdx.x, ldsraw);
 }
 
 } // namespace
@@ -836,7 +840,9 @@ hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *
         k.payload_out = payload_out; k.payload_frame_bytes = payload_frame_bytes; k.block0_out = block0_out; k.nframes = nframes;
         k.stagger = d.stagger; k.stagger_div = d.stagger_div;
         k.indices = indices_dev; k.explog = explog; k.max_rows = max_rows; k.strict = strict; k.stats = stats;
-        hipLaunchKernelGGL(gf_decode128_fft_plan_kernel, dim3(nframes), dim3(GF_NT), 0, stream, k);
+        k.srcmap = d.srcmap; k.restored = d.restored; k.restored_rows = d.restored_rows;
+        if (k.srcmap) hipLaunchKernelGGL(gf_decode128_fft_plan_kernel<true>, dim3(nframes), dim3(GF_NT), 0, stream, k);
+        else hipLaunchKernelGGL(gf_decode128_fft_plan_kernel<false>, dim3(nframes), dim3(GF_NT), 0, stream, k);
         return hipGetLastError();
     }
     DecPlanArgs p;
@@ -856,6 +862,7 @@ hipError_t launch_fec_decode_device_plan(const DecodeBuffers &d, const uint8_t *
         k.payload_out = payload_out; k.payload_frame_bytes = payload_frame_bytes; k.block0_out = block0_out; k.nframes = nframes;
         k.stagger = d.stagger; k.stagger_div = d.stagger_div;
         k.indices = nullptr; k.explog = nullptr; k.max_rows = max_rows; k.strict = strict; k.stats = stats;
+        k.srcmap = nullptr; k.restored = nullptr; k.restored_rows = 0;
         if (d.use_fft && d.fft_tables) hipLaunchKernelGGL(gf_decode128_fft_kernel, dim3(nframes), dim3(GF_NT), 0, stream, k);
         else hipLaunchKernelGGL(gf_decode128_kernel, dim3(2 * nframes), dim3(GF_NT), 0, stream, k);
         e = hipGetLastError();

@@ -46,11 +46,24 @@ template <int L, int WPW> __global__ __launch_bounds__(WNT * WPW) void interp_wa
     if (seg >= a.nseg) return;
     interp_wave_segment<L>(a, seg, blockIdx.y, lds[w]);
 }
+// ... with its input gathered through the Tx decoder's position map (InterpArgs::gmap)
+template <int L, int WPW> __global__ __launch_bounds__(WNT * WPW) void interp_wave_gather_kernel(InterpArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int lds[WPW][WGeo<(L == 6) ? 5 : L>::ldsDw];
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int seg = (int)blockIdx.x * WPW + w;
+    if (seg >= a.nseg) return;
+    interp_wave_segment<L, true>(a, seg, blockIdx.y, lds[w]);
+}
 
 template <int L> hipError_t launch_w(const InterpArgs &a, hipStream_t stream)
 {
     constexpr int WPW = 4;
-    if ((size_t)a.nseg * (size_t)a.nstreams >= 4096)
+    const bool four = (size_t)a.nseg * (size_t)a.nstreams >= 4096;
+    if (a.gmap) {
+        if (four) hipLaunchKernelGGL((interp_wave_gather_kernel<L, WPW>), dim3((a.nseg + WPW - 1) / WPW, a.nstreams), dim3(WNT * WPW), 0, stream, a);
+        else hipLaunchKernelGGL((interp_wave_gather_kernel<L, 1>), dim3(a.nseg, a.nstreams), dim3(WNT), 0, stream, a);
+    } else if (four)
         hipLaunchKernelGGL((interp_wave_kernel<L, WPW>), dim3((a.nseg + WPW - 1) / WPW, a.nstreams), dim3(WNT * WPW), 0, stream, a);
     else
         hipLaunchKernelGGL((interp_wave_kernel<L, 1>), dim3(a.nseg, a.nstreams), dim3(WNT), 0, stream, a);

@@ -272,6 +272,64 @@ template <class G, int S = 0> __device__ __forceinline__ void wstate_store(const
     if constexpr (S + 1 < G::NS) wstate_store<G, S + 1>(lds, lane, st);
 }
 
+// Where a wave's input comes from.  Contiguous: the stream is a.in.  Gather (the Tx pipe without the decoder's copy, InterpArgs::gmap):
+// sample g of the stream is dword `col` of block `blk` of frame `f`, (f, blk, col) = (g / 16129, 1 + g % 16129 / 127, g % 127), and the
+// block lies where the decoder's map says -- in the received frames (arrival order) or among the restored blocks.
+template <bool GATHER> struct WSrc;
+template <> struct WSrc<false> {
+    const unsigned *in;
+    __device__ __forceinline__ WSrc(const InterpArgs &a, int stream) : in(reinterpret_cast<const unsigned *>(a.in) + (size_t)stream * a.in_stride) {}
+    __device__ __forceinline__ bool aligned16() const { return (reinterpret_cast<uintptr_t>(in) & 15u) == 0; }
+    __device__ __forceinline__ unsigned ld1(size_t g) const { return SDRHIP_STREAM_LOAD(in + g); }
+    // the lane's 4 samples of pair p of the segment: one 16-byte load
+    __device__ __forceinline__ void seek(size_t) {}
+    __device__ __forceinline__ uint4_t ld4(size_t g) { return SDRHIP_STREAM_LOAD(reinterpret_cast<const uint4_t *>(in + g)); }
+};
+template <> struct WSrc<true> {
+    const unsigned *gmap;
+    const uint8_t *grx, *grest;
+    unsigned fbase, flast;   // first / last frame (absolute index) of the stream
+    unsigned f, blk, col;    // where the lane's running position (seek / ld4) stands
+    __device__ __forceinline__ WSrc(const InterpArgs &a, int stream)
+        : gmap(a.gmap), grx(a.grx), grest(a.grest), fbase((unsigned)stream * (unsigned)a.gframes), flast((unsigned)stream * (unsigned)a.gframes + (unsigned)a.gframes - 1u), f(0), blk(1), col(0) {}
+    __device__ __forceinline__ bool aligned16() const { return true; }
+    __device__ __forceinline__ const unsigned *block(unsigned ff, unsigned bb) const
+    {
+        const unsigned code = gmap[(size_t)ff * 128u + bb];
+        const uint8_t *p = (code >> 31) ? grest + (size_t)(code & 0x7fffffffu) * 508u : grx + (size_t)code * 512u + 4u;
+        return reinterpret_cast<const unsigned *>(p);
+    }
+    __device__ __forceinline__ unsigned ld1(size_t g) const
+    {
+        const unsigned gi = (unsigned)g, fr = gi / 16129u, r = gi - fr * 16129u, b = r / 127u;
+        return SDRHIP_STREAM_LOAD(block(fbase + fr, b + 1u) + (r - b * 127u));
+    }
+    __device__ __forceinline__ void seek(size_t g)
+    {
+        const unsigned gi = (unsigned)g, fr = gi / 16129u, r = gi - fr * 16129u, b = r / 127u;
+        f = fbase + fr; blk = b + 1u; col = r - b * 127u;
+    }
+    // the 4 samples at the running position (they may straddle a block, and with it a frame), then the position moves on by 256
+    // samples = two blocks and two samples (a pair of K5w's input blocks further)
+    __device__ __forceinline__ uint4_t ld4(size_t)
+    {
+        const unsigned *pa = block(f, blk);
+        unsigned nb = blk + 1u, nf = f;
+        if (nb > 127u) { nb = 1u; nf = f + 1u; }
+        if (nf > flast) nf = flast; // (past the stream's last frame: never selected -- the segment's samples end in front of it)
+        const unsigned *pb = block(nf, nb) - 127; // (indexed with col + k >= 127)
+        uint4_t v;
+        v.x = SDRHIP_STREAM_LOAD(pa + col);
+        v.y = SDRHIP_STREAM_LOAD((col + 1u < 127u ? pa : pb) + col + 1u);
+        v.z = SDRHIP_STREAM_LOAD((col + 2u < 127u ? pa : pb) + col + 2u);
+        v.w = SDRHIP_STREAM_LOAD((col + 3u < 127u ? pa : pb) + col + 3u);
+        col += 2u; blk += 2u;
+        if (col >= 127u) { col -= 127u; blk += 1u; }
+        if (blk > 127u) { blk -= 127u; f += 1u; }
+        return v;
+    }
+};
+
 // one segment (seg of a.nseg, a.nsub_per_seg blocks of 128 inputs each) of one stream, on one wave; L >= 2
 //
 // WHERE THE INPUT LOADS GO decides this kernel (tools/store_load_mix.hip, tools/experiments_r04/): a streaming store pattern
@@ -281,13 +339,13 @@ template <class G, int S = 0> __device__ __forceinline__ void wstate_store(const
 // segment (<= 16 blocks = 8 KiB: eight global_load_dwordx4) in front of everything else, parks it in 32 accumulation registers
 // (nothing else uses them, so nothing moves them) and issues nothing but stores from then on; a pair of blocks at a time comes
 // back through v_accvgpr_read, is de-interleaved into packed I / Q pairs and staged in LDS.
-template <int L> __device__ __forceinline__ void interp_wave_segment(const InterpArgs &a, int seg, int stream, int *lds)
+template <int L, bool GATHER = false> __device__ __forceinline__ void interp_wave_segment(const InterpArgs &a, int seg, int stream, int *lds)
 {
     constexpr int NS = (L == 6) ? 5 : L;
     static_assert(NS >= 2, "interpolate2 has a single stage: K5");
     using G = WGeo<NS>;
     const int lane = threadIdx.x & 63;
-    const unsigned *in = reinterpret_cast<const unsigned *>(a.in) + (size_t)stream * a.in_stride;
+    WSrc<GATHER> src(a, stream);
     const size_t seg_len = (size_t)a.nsub_per_seg * WB;
     const size_t seg_start = (size_t)seg * seg_len;
     size_t seg_end = seg_start + seg_len;
@@ -295,7 +353,7 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
 
     unsigned *p0 = reinterpret_cast<unsigned *>(lds);
     // ---- the segment's whole blocks, pair by pair, into AGPRs (pairs beyond the segment: not loaded, never read)
-    const bool al16 = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+    const bool al16 = src.aligned16();
     const int npairs = al16 ? (int)((seg_end - seg_start) / (2 * WB) < (size_t)WPAIRS ? (seg_end - seg_start) / (2 * WB) : (size_t)WPAIRS) : 0;
     unsigned A[4 * WPAIRS];
     const int32_t *stc = a.state_cur + (size_t)stream * INT_STATE_WORDS;
@@ -303,17 +361,18 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
     int sv[NS];
     {
         uint4_t v[WPAIRS];
+        src.seek(seg_start + 4 * (size_t)lane);
 #pragma unroll
         for (int p = 0; p < WPAIRS; ++p) { // all of them back to back: ONE cluster of reads per wave
             v[p] = (uint4_t){0u, 0u, 0u, 0u};
-            if (p < npairs) v[p] = SDRHIP_STREAM_LOAD(reinterpret_cast<const uint4_t *>(in + seg_start + (size_t)p * 2 * WB + 4 * lane));
+            if (p < npairs) v[p] = src.ld4(seg_start + (size_t)p * 2 * WB + 4 * lane);
         }
         // the warm-up's samples and the bank state: behind the cluster and in flight with it (three round trips in a row --
         // cluster, state, warm-up -- at the start of every wave before; tools/experiments_r04 batch 24)
         if (seg != 0) {
-            const unsigned *wp = in + (seg_start - WWARM) + 2 * lane;
-            if (2 * lane < WWARM) wv.x = SDRHIP_STREAM_LOAD(wp);
-            if (2 * lane + 1 < WWARM) wv.y = SDRHIP_STREAM_LOAD(wp + 1);
+            const size_t wg = (seg_start - WWARM) + 2 * (size_t)lane;
+            if (2 * lane < WWARM) wv.x = src.ld1(wg);
+            if (2 * lane + 1 < WWARM) wv.y = src.ld1(wg + 1);
         }
         wstate_fetch<G>(sv, lane, stc, seg != 0);
 #pragma unroll
@@ -354,8 +413,8 @@ template <int L> __device__ __forceinline__ void interp_wave_segment(const Inter
     auto single = [&](size_t pos, int cnt, bool store) {
         const int m = 2 * lane;
         uint2_t v = (uint2_t){0u, 0u};
-        if (m < cnt) v.x = SDRHIP_STREAM_LOAD(in + pos + m);
-        if (m + 1 < cnt) v.y = SDRHIP_STREAM_LOAD(in + pos + m + 1);
+        if (m < cnt) v.x = src.ld1(pos + m);
+        if (m + 1 < cnt) v.y = src.ld1(pos + m + 1);
         single_v(v, cnt, store);
     };
 

@@ -120,7 +120,7 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
         // sdrhip_ctx_set_option()
         static const char *const keys[][2] = {{"SDRHIP_DECIM_PATH", "decim_path"}, {"SDRHIP_MFMA_SPAN", "mfma_span"}, {"SDRHIP_MFMA_MIN", "mfma_min"},
                                               {"SDRHIP_INTERP_PATH", "interp_path"}, {"SDRHIP_INTERP_SPAN", "interp_span"}, {"SDRHIP_RX_FUSED", "rx_fused"}, {"SDRHIP_RX_DIRECT", "rx_direct"},
-                                              {"SDRHIP_DEC_PATH", "dec_path"}, {"SDRHIP_ENC_PATH", "enc_path"}, {"SDRHIP_ENC_MIN_ROWS", "enc_min_rows"}, {"SDRHIP_MFMA_RING", "mfma_ring"}, {"SDRHIP_TX_OVERLAP", "tx_overlap"}, {"SDRHIP_RX_WINDOW", "rx_window"}, {"SDRHIP_FEC_STAGGER", "fec_stagger"}, {"SDRHIP_FEC_STAGGER_MOD", "fec_stagger_mod"}, {"SDRHIP_DEC_PLAN", "dec_plan"}};
+                                              {"SDRHIP_DEC_PATH", "dec_path"}, {"SDRHIP_ENC_PATH", "enc_path"}, {"SDRHIP_ENC_MIN_ROWS", "enc_min_rows"}, {"SDRHIP_MFMA_RING", "mfma_ring"}, {"SDRHIP_TX_OVERLAP", "tx_overlap"}, {"SDRHIP_RX_WINDOW", "rx_window"}, {"SDRHIP_FEC_STAGGER", "fec_stagger"}, {"SDRHIP_FEC_STAGGER_MOD", "fec_stagger_mod"}, {"SDRHIP_DEC_PLAN", "dec_plan"}, {"SDRHIP_TX_GATHER", "tx_gather"}};
         for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); ++i)
             if (const char *v = getenv(keys[i][0])) (void)sdrhip_ctx_set_option(c, keys[i][1], v);
     }
@@ -220,6 +220,7 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
     else if (k == "tx_overlap" && isnum && num <= 1) c->opt.tx_overlap = (int)num;
     else if (k == "fec_stagger" && isnum && num <= 64) c->opt.fec_stagger = (int)num;
     else if (k == "fec_stagger_mod" && isnum && num <= 16) c->opt.fec_stagger_mod = (int)num;
+    else if (k == "tx_gather" && isnum && num <= 1) c->opt.tx_gather = (int)num;
     else if (k == "dec_plan") {
         if (v == "fused") c->opt.dec_fused_plan = 1;
         else if (v == "kernel") c->opt.dec_fused_plan = 0;

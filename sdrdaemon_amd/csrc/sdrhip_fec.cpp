@@ -77,9 +77,16 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
 // scatter of the received originals, the matrix apply.  No host synchronisation, no limit on the number of distinct
 // erasure patterns in a batch.  indices: optional HOST array (nframes x 128 block indices in arrival order); NULL = the
 // kernels read header.blockIndex of the super blocks themselves (:147).
-int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
-                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out, const DecodeSide *side)
+bool fec_decode_gather_ok(const sdrhip_ctx *c)
 {
+    // (the conditions under which launch_fec_decode_device_plan takes its one-launch branch)
+    return c->opt.dec_syndrome && c->opt.enc_fft && c->enc_fft && c->opt.dec_fused_plan && c->opt.dec_max_rows <= 32;
+}
+
+int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
+                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out, const DecodeSide *side, const DecodeGather *gather)
+{
+    if (gather && !fec_decode_gather_ok(c)) return fail(SDRHIP_EINVAL, "internal: no-copy decode without the fused-plan decoder");
     // (side: a pipelined Tx pipe decodes on the context's second stream with work buffers of its own, so that the context's
     // shared ones stay free for whatever runs on the first stream meanwhile)
     hipStream_t st = side ? side->stream : c->stream;
@@ -106,6 +113,7 @@ int fec_decode_device(sdrhip_ctx *c, const uint8_t *rx, size_t rx_frame_bytes, c
     d.fft_tables = c->enc_fft; d.use_fft = c->opt.enc_fft;
     d.stagger = c->opt.fec_stagger; d.stagger_div = c->opt.fec_stagger_mod ? -c->opt.fec_stagger_mod : c->n_cu;
     d.fused_plan = c->opt.dec_fused_plan;
+    d.srcmap = gather ? gather->srcmap : nullptr; d.restored = gather ? gather->restored : nullptr; d.restored_rows = gather ? gather->rows : 0;
     const uint8_t *idx_dev = nullptr;
     if (indices) {
         const size_t nb = nframes * (size_t)SDRHIP_NB_ORIGINAL;

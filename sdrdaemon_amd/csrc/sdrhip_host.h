@@ -77,8 +77,14 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
 // the context's second stream (created on first use; non-blocking, so that it never synchronises with a NULL caller stream)
 int ctx_stream2(sdrhip_ctx *c, hipStream_t *out);
 bool decimate_mfma_applies(const sdrhip_decimators *d, int log2decim, int fcpos, size_t n_in);
+struct InterpGather { // InterpArgs::gmap / grx / grest / gframes
+    const unsigned *map;
+    const uint8_t *rx, *restored;
+    int frames;
+};
+bool interpolate_gather_ok(const sdrhip_ctx *c, int log2interp); // K5w serves this ratio (interpolate4 .. 64, interp_path != valu)
 int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *in, size_t n_in, size_t in_stride, int16_t *out,
-                       size_t out_stride, size_t *n_out);
+                       size_t out_stride, size_t *n_out, const InterpGather *gather = nullptr);
 // frames/recovery on the device; recovery slots may be interleaved with the frames
 // (rec_frame_bytes = stride between the recovery areas of consecutive frames)
 // frame_list_dev (optional, device): groups of GF_FRAMES_PER_GROUP frame indices (-1 = none), ngroups of them
@@ -105,8 +111,18 @@ struct DecodeSide { // decode on another stream than the context's, with the cal
     DevBuf *plan, *idx;
     PinnedBuf *pin;
 };
+// no-copy decode (round 6, the Tx pipe in front of K5w): the received originals stay in rx, the restored blocks go to `restored`
+// (nframes * rows + 1 slots of 508 bytes, the last one all zeros), `srcmap` ([nframes][128]) tells the interpolator where every block
+// lies (InterpArgs::gmap).  Only when fec_decode_gather_ok(): the fused-plan FFT decoder is the one kernel that writes the map.
+struct DecodeGather {
+    unsigned *srcmap;
+    uint8_t *restored;
+    int rows;
+};
+bool fec_decode_gather_ok(const sdrhip_ctx *c);
 int fec_decode_device(sdrhip_ctx *ctx, const uint8_t *rx, size_t rx_frame_bytes, const uint8_t *indices, size_t nframes,
-                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out, const DecodeSide *side = nullptr);
+                      uint8_t *payload_out, size_t payload_frame_bytes, uint8_t *block0_out, const DecodeSide *side = nullptr,
+                      const DecodeGather *gather = nullptr);
 
 } // namespace sdrhip
 
@@ -134,6 +150,11 @@ struct CtxOptions {
     int enc_min_rows = 1;                  // ... the FFT from this many recovery blocks on (the generic matrix kernel below)
     int fec_stagger_mod = 0;               // 0: phase = resident round (workgroup / CUs); m > 0: phase = workgroup mod m (experiment)
     int fec_stagger = 0;                   // staggered start of the FFT encoder's / decoder's workgroups, units of 1024 clocks per resident round (0 = off)
+    // Tx pipe without the decoder's copy (built in round 6): immediate mode on K5w with the fused-plan decoder, the
+    // interpolator gathers the received originals through the decoder's position map.  OFF by default: the decoder gets 11 us
+    // faster per 1024 frames (0.0822 -> 0.0710 ms), the interpolator 62 us SLOWER (0.2354 -> 0.2974 ms: 48 load instructions per
+    // wave instead of 8 in front of its store stream, profiles/r06_tx_gather_ab.txt)
+    int tx_gather = 0;
     int dec_fused_plan = 1;                // batched decode with dec_max_rows <= 32 on the FFT decoder: the plan is made inside the decoder's launch (0: gf_decode_plan_kernel in front)
     int dec_syndrome = 1;                  // batched CM256 decode: syndrome kernel (1) or the dense matrix kernel alone (0)
     int dec_strict = 0;                    // batched decode delivers only what the reference's copy-back loop delivers (SDRdaemonFECBuffer.cpp:204-211)

@@ -198,8 +198,14 @@ struct InterpArgs {
     int32_t *state_next;
     int nstreams;
     int nsub_per_seg, nseg;
-    // (the fused Tx pipe needs no special input mode: the decoder's 127 x 508 byte payload of a frame is
-    // contiguous, i.e. already the linear sample layout)
+    // (the Tx pipe's decoded payload -- 127 x 508 bytes per frame, contiguous -- is already the linear sample layout: `in`.)
+    // Gather mode (round 6, K5w only; gmap != NULL): the Tx pipe's decoder does NOT copy the received originals; stream s is
+    // gframes frames of 127 blocks of 127 samples, block b (1..127) of frame f lies where gmap[(s * gframes + f) * 128 + b] says:
+    // bit 31 clear: super block slot (payload at +4) of the received frames grx, 512 bytes apart; bit 31 set: 508-byte slot of the
+    // restored blocks grest (the decoder's output; its last slot is all zeros: blocks that never came and cannot be restored)
+    const unsigned *gmap;
+    const uint8_t *grx, *grest;
+    int gframes;
 };
 hipError_t launch_interpolate(int log2interp, const InterpArgs &a, hipStream_t stream);
 void plan_interpolate(int log2interp, size_t n_in, int nstreams, int *nsub_per_seg, int *nseg);
@@ -309,6 +315,10 @@ struct DecodeBuffers {
     int use_fft;
     int stagger, stagger_div;   // staggered start of the FFT decoder's workgroups (see Enc128Args::stagger)
     int fused_plan;             // 1: frames that can carry at most DEC128_MAXN recovery blocks are planned by the decoder's own workgroups (one launch)
+    // no-copy mode (only honoured by the fused-plan launch: the caller checks fec_decode_gather_ok()): see Dec128Args::srcmap
+    unsigned *srcmap;
+    uint8_t *restored;
+    int restored_rows;
     static size_t bytes(size_t nframes) { return nframes * (128 * 128 + 4 * 128 * sizeof(int16_t) + 2 * sizeof(int32_t) + DECODE_PLAN2_BYTES) + 64; }
 };
 // plan + scatter + apply, all on the stream, no host synchronisation; max_rows = upper bound of the recovery blocks a

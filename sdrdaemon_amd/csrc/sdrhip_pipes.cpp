@@ -60,12 +60,15 @@ extern "C" int sdrhip_interpolators_reset(sdrhip_interpolators *p)
 }
 
 namespace sdrhip {
+bool interpolate_gather_ok(const sdrhip_ctx *c, int log2interp) { return c->opt.interp_wave && log2interp >= 2; }
+
 int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *in, size_t n_in, size_t in_stride, int16_t *out,
-                       size_t out_stride, size_t *n_out)
+                       size_t out_stride, size_t *n_out, const InterpGather *gather)
 {
     sdrhip_ctx *c = p->ctx;
     if (n_out) *n_out = n_in << log2interp;
     if (n_in == 0) return SDRHIP_OK;
+    if (gather && !interpolate_gather_ok(p->ctx, log2interp)) return fail(SDRHIP_EINVAL, "internal: gathered input needs the wave interpolator");
     if (log2interp == 0) { // Upsampler::process m_interp == 0: samples_out = samples_in (Upsampler.cpp:54-57)
         HIP_TRY(hipMemcpy2DAsync(out, out_stride * 4, in, in_stride * 4, n_in * 4, p->nstreams, hipMemcpyDeviceToDevice, c->stream));
         return SDRHIP_OK;
@@ -75,6 +78,7 @@ int interpolate_device(sdrhip_interpolators *p, int log2interp, const int16_t *i
     a.in = in; a.out = out; a.in_stride = in_stride; a.out_stride = out_stride; a.n_in = n_in;
     a.state_cur = p->state[p->cur]; a.state_next = p->state[p->cur ^ 1];
     a.nstreams = p->nstreams;
+    if (gather) { a.gmap = gather->map; a.grx = gather->rx; a.grest = gather->restored; a.gframes = gather->frames; }
     // SDRHIP_INTERP_PATH = wave (K5w, default) | valu (K5); SDRHIP_INTERP_SPAN = segment length in inputs (tests)
     const bool use_wave = c->opt.interp_wave && log2interp >= 2;
     if (use_wave) plan_interpolate_wave(log2interp, n_in, p->nstreams, c->n_cu, c->opt.interp_span, &a.nsub_per_seg, &a.nseg);
@@ -832,6 +836,8 @@ struct sdrhip_tx {
     int log2interp;
     sdrhip_interpolators *itp;
     DevBuf rxbuf, payload[2], outbuf;
+    DevBuf srcmap, restored;  // no-copy mode (tx_gather): the decoder's position map and restored blocks, read by K5w's gather variant
+    size_t restored_slots = 0; // slots `restored` was zero-terminated for (its last slot must read zero)
     // ---- pipelined mode (sdrhip_tx_set_pipelined): a call decodes ITS batch into payload[psel] -- on the context's second stream,
     // with work buffers of its own -- while the first stream interpolates the batch the PREVIOUS call decoded (payload[psel ^ 1]);
     // the samples are delivered one call late, like SDRdaemonFECBuffer delivers a frame when the next one begins (.cpp:133-139)
@@ -895,6 +901,7 @@ extern "C" void sdrhip_tx_destroy(sdrhip_tx *tx)
     if (tx->ctx->stream2) (void)hipStreamSynchronize(tx->ctx->stream2); // (a decode of the pipelined mode may still run there)
     sdrhip_interpolators_destroy(tx->itp); // (synchronises the first stream)
     tx->rxbuf.release(); tx->payload[0].release(); tx->payload[1].release(); tx->outbuf.release();
+    tx->srcmap.release(); tx->restored.release();
     tx->plan_own.release(); tx->idx_own.release(); tx->pin_own.release();
     for (auto &b : tx->abatch) {
         if (b.done) { (void)hipEventSynchronize(b.done); (void)hipEventDestroy(b.done); }
@@ -942,8 +949,37 @@ int tx_decode(sdrhip_tx *tx, const uint8_t *drx, const uint8_t *indices, size_t 
     return SDRHIP_OK;
 }
 
+// no-copy mode of a batch (round 6): the decoder leaves the received originals in drx and writes only the restored blocks + a map;
+// the wave interpolator gathers through the map.  Applies to immediate calls and the asynchronous entry (the received frames must
+// outlive the interpolator: a pipelined call interpolates one call LATE, when a device caller may have reused its buffer).
+bool tx_gather_applies(const sdrhip_tx *tx, int log2interp)
+{
+    const sdrhip_ctx *c = tx->ctx;
+    return c->opt.tx_gather && !tx->pipelined && interpolate_gather_ok(c, log2interp) && fec_decode_gather_ok(c);
+}
+int tx_decode_gather(sdrhip_tx *tx, const uint8_t *drx, const uint8_t *indices, size_t nframes, InterpGather *g, uint8_t *block0 = nullptr)
+{
+    sdrhip_ctx *c = tx->ctx;
+    const size_t F = (size_t)tx->nstreams * nframes, rows = (size_t)c->opt.dec_max_rows, slots = F * rows + 1;
+    if (F * 128 >= 0x7fffffffu || slots >= 0x7fffffffu) return fail(SDRHIP_EINVAL, "tx: too many frames in one call");
+    int rc;
+    if ((rc = tx->srcmap.reserve(F * 128 * sizeof(unsigned)))) return rc;
+    if ((rc = tx->restored.reserve(slots * SDRHIP_BLOCK_BYTES))) return rc;
+    if (tx->restored_slots != slots) { // (the all-zero slot behind the last frame's: wherever it lies for this batch size)
+        HIP_TRY(hipMemsetAsync(tx->restored.as<uint8_t>() + (slots - 1) * SDRHIP_BLOCK_BYTES, 0, SDRHIP_BLOCK_BYTES, c->stream));
+        tx->restored_slots = slots;
+    }
+    DecodeGather dg;
+    dg.srcmap = tx->srcmap.as<unsigned>(); dg.restored = tx->restored.as<uint8_t>(); dg.rows = (int)rows;
+    const size_t fb = (size_t)SDRHIP_NB_ORIGINAL * SDRHIP_UDPSIZE;
+    if ((rc = fec_decode_device(c, drx, fb, indices, F, nullptr, 0, block0, nullptr, &dg))) return rc;
+    g->map = dg.srcmap; g->rx = drx; g->restored = dg.restored; g->frames = (int)nframes;
+    return SDRHIP_OK;
+}
+
 // interpolate a decoded batch on the first stream into the caller's buffer (host: through outbuf + a download)
-int tx_interpolate(sdrhip_tx *tx, int log2interp, const DevBuf &pay, size_t n_payload, size_t pstride, int16_t *iq_out, size_t out_stride, int mem)
+int tx_interpolate(sdrhip_tx *tx, int log2interp, const DevBuf &pay, size_t n_payload, size_t pstride, int16_t *iq_out, size_t out_stride, int mem,
+                   const InterpGather *gather = nullptr)
 {
     sdrhip_ctx *c = tx->ctx;
     const int S = tx->nstreams;
@@ -956,7 +992,7 @@ int tx_interpolate(sdrhip_tx *tx, int log2interp, const DevBuf &pay, size_t n_pa
         if ((rc = tx->outbuf.reserve((size_t)S * dos * 4 + 16))) return rc;
         dout = tx->outbuf.as<int16_t>();
     }
-    if ((rc = interpolate_device(tx->itp, log2interp, pay.as<int16_t>(), n_payload, pstride, dout, dos, nullptr))) return rc;
+    if ((rc = interpolate_device(tx->itp, log2interp, gather ? nullptr : pay.as<int16_t>(), n_payload, pstride, dout, dos, nullptr, gather))) return rc;
     if (mem == SDRHIP_MEM_HOST)
         HIP_TRY(hipMemcpy2DAsync(iq_out, out_stride * 4, dout, dos * 4, n_res * 4, S, hipMemcpyDeviceToHost, c->stream));
     return SDRHIP_OK;
@@ -1081,6 +1117,14 @@ extern "C" int sdrhip_tx_process(sdrhip_tx *tx, const uint8_t *rx, const uint8_t
     } else {
         if (!aligned16(iq_out) || (S > 1 && (out_stride & 3))) return fail(SDRHIP_EALIGN, "tx_process: device output must be 16-byte aligned");
     }
+    if (tx_gather_applies(tx, tx->log2interp)) {
+        // no-copy: decode (restored blocks + map only), then the interpolator reads the received frames through the map
+        InterpGather g;
+        if ((rc = tx_decode_gather(tx, drx, indices, nframes, &g))) return rc;
+        if ((rc = tx_interpolate(tx, tx->log2interp, tx->payload[0], n_payload, pstride, iq_out, out_stride, mem, &g))) return rc;
+        if (mem == SDRHIP_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream));
+        return SDRHIP_OK;
+    }
     // decode all S * nframes frames in one batch: payload [S][nframes][127 * 508] = [S][n_payload] samples
     if ((rc = tx->payload[0].reserve((size_t)S * pstride * 4 + 16))) return rc;
     if ((rc = tx_decode(tx, drx, indices, nframes, tx->payload[0], pstride, nullptr))) return rc;
@@ -1133,7 +1177,8 @@ extern "C" int sdrhip_tx_submit(sdrhip_tx *tx, const uint8_t *rx, const uint8_t 
     if ((rc = b.dout.reserve((size_t)S * dos * 4 + 16))) return rc;
     if ((rc = b.db0.reserve(b0_bytes))) return rc;
     if ((rc = b.out.reserve((size_t)S * dos * 4 + b0_bytes))) return rc;
-    if ((rc = tx->payload[0].reserve((size_t)S * pstride * 4 + 16))) return rc;
+    const bool gather = tx_gather_applies(tx, tx->log2interp);
+    if (!gather && (rc = tx->payload[0].reserve((size_t)S * pstride * 4 + 16))) return rc;
     if (!b.done && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) { b.done = nullptr; return fail(SDRHIP_EDEVICE, "hipEventCreate"); }
     const uint8_t *src = rx;
     size_t sstride = rx_stride_bytes;
@@ -1145,8 +1190,15 @@ extern "C" int sdrhip_tx_submit(sdrhip_tx *tx, const uint8_t *rx, const uint8_t 
     if (S == 1) HIP_TRY(hipMemcpyAsync(b.din.p, src, row, hipMemcpyHostToDevice, c->stream));
     else HIP_TRY(hipMemcpy2DAsync(b.din.p, row, src, sstride, row, S, hipMemcpyHostToDevice, c->stream));
     if (src != rx) b.in.mark(c->stream);
-    if ((rc = tx_decode(tx, b.din.as<uint8_t>(), indices, nframes, tx->payload[0], pstride, nullptr, b.db0.as<uint8_t>()))) return rc;
-    if ((rc = interpolate_device(tx->itp, tx->log2interp, tx->payload[0].as<int16_t>(), n_payload, pstride, b.dout.as<int16_t>(), dos, nullptr))) return rc;
+    if (gather) {
+        // (the batch's received frames live in b.din until it is collected: the interpolator reads them in place)
+        InterpGather g;
+        if ((rc = tx_decode_gather(tx, b.din.as<uint8_t>(), indices, nframes, &g, b.db0.as<uint8_t>()))) return rc;
+        if ((rc = interpolate_device(tx->itp, tx->log2interp, nullptr, n_payload, pstride, b.dout.as<int16_t>(), dos, nullptr, &g))) return rc;
+    } else {
+        if ((rc = tx_decode(tx, b.din.as<uint8_t>(), indices, nframes, tx->payload[0], pstride, nullptr, b.db0.as<uint8_t>()))) return rc;
+        if ((rc = interpolate_device(tx->itp, tx->log2interp, tx->payload[0].as<int16_t>(), n_payload, pstride, b.dout.as<int16_t>(), dos, nullptr))) return rc;
+    }
     // (from here on the interpolator's state has advanced: a failure loses the batch, it is never replayed)
     hipError_t e = hipMemcpyAsync(b.out.p, b.dout.p, (size_t)S * dos * 4, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(b.out.as<char>() + (size_t)S * dos * 4, b.db0.p, b0_bytes, hipMemcpyDeviceToHost, c->stream);

@@ -151,6 +151,91 @@ def test_tx_pipe_matches_reference_chain(ctx, oracle):
         assert np.array_equal(iq, oracle.interpolators().interpolate(log2, y)), log2
 
 
+@pytest.mark.parametrize("strict", [0, 1])
+def test_tx_pipe_without_the_copy_equals_the_copying_pipe(ctx, oracle, strict):
+    """Round 6: with dec_max_rows <= 32 on the wave interpolator the Tx pipe CAN run without copying the received
+    originals -- the decoder writes only the restored blocks and a position map, interpolate4 .. 64 gather through it (option
+    tx_gather = 1; off by default: it measured slower).  Hostile
+    frames on three streams -- 0 .. 32 erasures, arrival order shuffled, recovery blocks interleaved, block 0 lost, cm256's XOR
+    shortcut on a non-parity row, a repeated original (the blocks that never came read zero), a frame that breaks the dec_max_rows
+    promise -- through ragged calls (1, 4 and 3 frames: segments straddle frames and calls), host and device memory, the
+    asynchronous entry with its meta blocks: the same samples as the copying pipe (tx_gather = 0), and the oracle chain's where the
+    frames are decodable."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    S, F, R = 3, 8, 32
+    rs = np.random.RandomState(99 + strict)
+    ys = [signals.noise(F * 16129, 500 + s) for s in range(S)]
+    rx = np.zeros((S, F, 128, 512), np.uint8)
+    good = np.ones((S, F), bool)
+    for s in range(S):
+        frames = oracle.framer(nb_fec_blocks=R).write(ys[s])
+        for f in range(F):
+            allb = np.concatenate([frames[f], oracle.frame_encode(frames[f], 64)[:64]])
+            kind = (f + 3 * s) % 8
+            nlost = [0, 1, 3, 24, 32, 17, 9, 5][kind]
+            lost_o = sorted(rs.choice(128, nlost, replace=False).tolist())
+            if kind == 2:
+                lost_o[0] = 0
+                lost_o = sorted(set(lost_o))
+            rows = sorted(rs.choice(32, len(lost_o), replace=False).tolist())
+            if kind == 1:
+                rows = [int(rs.randint(1, 32))]
+                good[s, f] = lost_o[0] == 0  # (only block 0 may come out wrong without the samples noticing)
+            got = [i for i in range(128) if i not in lost_o]
+            rs.shuffle(got)
+            order = got + [128 + r for r in rows]
+            if kind == 5:
+                rs.shuffle(order)
+                good[s, f] = not strict
+            if kind == 6:
+                order[-1] = order[0]  # a repeated original: decode error, the missing blocks read zero
+                good[s, f] = False
+            if kind == 7 and s == 1:
+                order = [i for i in range(128) if i >= 33] + [128 + r for r in range(33)]  # 33 recovery blocks against a promise of 32
+                good[s, f] = False
+            rx[s, f] = allb[order]
+    cuts = [0, 1, 5, 8]
+    ctx.set_option("dec_max_rows", R)
+    ctx.set_option("dec_strict", strict)
+    try:
+        for log2 in (4, 2, 6):
+            outs = {}
+            for gather in (1, 0):
+                ctx.set_option("tx_gather", gather)
+                for dev in (False, True):
+                    tx = sd.TxPipe(ctx, S, log2)
+                    parts = []
+                    for a, b in zip(cuts[:-1], cuts[1:]):
+                        batch = np.ascontiguousarray(rx[:, a:b])
+                        o = tx.process(torch.from_numpy(batch).cuda() if dev else batch)
+                        parts.append(o.cpu().numpy() if dev else o)
+                    outs[(gather, dev)] = np.concatenate(parts, axis=1)
+            ref = outs[(0, False)]
+            for k, v in outs.items():
+                assert v.shape == ref.shape and np.array_equal(v, ref), (log2, k)
+            for s in range(S):
+                if good[s].all():
+                    assert np.array_equal(ref[s], oracle.interpolators().interpolate(log2, ys[s])), (log2, s)
+        # the asynchronous entry (meta blocks included), no-copy against copying
+        res = {}
+        for gather in (1, 0):
+            ctx.set_option("tx_gather", gather)
+            tx = sd.TxPipe(ctx, S, 4)
+            tx.set_async(depth=4)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                tx.submit(np.ascontiguousarray(rx[:, a:b]))
+            got = [tx.collect(wait=True, block0=True) for _ in range(3)]
+            res[gather] = (np.concatenate([g[0] for g in got], axis=1), np.concatenate([g[1] for g in got], axis=1))
+        assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1])
+    finally:
+        ctx.set_option("tx_gather", 0)
+        ctx.set_option("dec_max_rows", 128)
+        ctx.set_option("dec_strict", 0)
+
+
 def test_roundtrip_rx_to_tx_full_size_property(ctx):
     """BASELINE-size property (no oracle in the loop): encode -> erase 24 of 160 -> decode gives
     back the decimated stream for 64 frames x 4 streams."""

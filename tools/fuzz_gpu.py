@@ -60,6 +60,7 @@ while time.time() - t0 < budget and (max_it == 0 or it < max_it):
     ctx.set_option("rx_direct", int(rs.randint(0, 2)))       # matrix-core decimator inside the Rx pipe: frame-layout stores / stream order + framing pass
     ctx.set_option("enc_path", str(rs.choice(["fft", "fft", "karatsuba"])))  # CM256 128 + R encoder and the syndrome decoder's walk
     ctx.set_option("dec_path", str(rs.choice(["syndrome", "syndrome", "dense"])))
+    ctx.set_option("tx_gather", int(rs.choice([1, 1, 0])))                     # Tx pipe on K5w with the fused-plan decoder: no copy of the received originals / payload buffer in between
     ctx.set_option("dec_plan", str(rs.choice(["fused", "fused", "kernel"])))    # dec_max_rows <= 32 on the FFT decoder: the plan inside the decoder's launch / gf_decode_plan_kernel in front
     ctx.set_option("interp_path", str(rs.choice(["wave", "wave", "valu"])))     # K5w (default) / K5
     ctx.set_option("interp_span", int(rs.choice([0, 0, 128, 256, 640, 2048])))  # segment length in inputs (0 = the planner's)
