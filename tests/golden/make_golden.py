@@ -325,6 +325,8 @@ if __name__ == "__main__":
         ts_headline_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "tx_headline":
         tx_headline_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fec":
+        fec_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "long":
         long_golden()
     else:
