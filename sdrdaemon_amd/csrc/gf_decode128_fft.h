@@ -38,6 +38,9 @@ struct Dec128Scratch {
     unsigned long long mask[2][3];
 };
 static_assert(sizeof(Dec128Scratch) % 16 == 0, "scratch size");
+static_assert(offsetof(Dec128Scratch, lqx) == offsetof(Dec128Scratch, lpx) + 4 * DEC128_MAXN && offsetof(Dec128Scratch, lpy) == offsetof(Dec128Scratch, lpx) + 8 * DEC128_MAXN &&
+              offsetof(Dec128Scratch, lqy) == offsetof(Dec128Scratch, lpx) + 12 * DEC128_MAXN && offsetof(Dec128Scratch, log) == 512,
+              "dec128_plan clears the four logarithm sums as one array and loads exp + log as one 1 KiB block");
 constexpr int DEC128_FFT_FUSED_LDS_BYTES = DEC128_FFT_LDS_BYTES + (int)sizeof(Dec128Scratch);
 
 __device__ __forceinline__ void dec128_plan(const Dec128Args &a, int fr, Dec128Plan *pl, Dec128Scratch *s, unsigned char *ldsraw)
