@@ -18,6 +18,14 @@ static_assert(DEC128_PLAN_BYTES % 16 == 0 && DEC128_MAXN == 32, "plan record lay
 
 template <int HF, bool FUSED, bool NOCOPY> __device__ __forceinline__ void gf_decode128_fft_wave(const Dec128Args &a, int fr, unsigned char *ldsraw, int ch);
 
+// The received frames are read exactly once: their loads are non-temporal (buffer cache policy bit 1 = nt on gfx950).  With the default
+// policy every line of the burst allocates in the L2 / Infinity Cache and evicts a dirty line of whatever ran before (in the Tx pipe the
+// interpolator's 1 GB of output): tools/fec_burst_probe.hip -- the workgroups' 67 MB behind a 1-GiB store stream: 28.1 us, nt 13.7 us;
+// with the copy stores 44.9 / 30.2 us (nt STORES: no gain, 33.4).
+#ifndef DEC_LOAD_AUX
+#define DEC_LOAD_AUX 2
+#endif
+
 // ---- the frame's plan made by the decoder's own workgroup (round 6: FUSED).  gf_decode_plan_kernel (gf_kernels.hip) used to run as a
 // launch of its own in front of this kernel: 16 us per 1024 frames, serial, most of it one workgroup's latency chain.  When no frame
 // can carry more than DEC128_MAXN recovery blocks (the caller's dec_max_rows promise <= 32: the sender's fecblk) everything a frame's
@@ -49,20 +57,38 @@ __device__ __forceinline__ void dec128_plan(const Dec128Args &a, int fr, Dec128P
     const int tid = threadIdx.x;
     // the frame's block indices first (the one load the whole chain waits for: 128 header bytes, 512 bytes apart), the tables behind them
     int b = 0;
-    if (tid < K) b = a.indices ? a.indices[(size_t)fr * K + tid] : a.rx[(size_t)fr * a.rx_frame_bytes + (size_t)tid * 512 + 2];
+#ifndef DEC_HDR_NT
+#define DEC_HDR_NT 1 // (the header bytes non-temporal too, although their lines are read again by the data loads: this barrier 8.1 -> 4.4 us, decode -2.8 us)
+#endif
+    if (tid < K) {
+        if (a.indices) b = a.indices[(size_t)fr * K + tid];
+        else if (DEC_HDR_NT) b = __builtin_amdgcn_raw_buffer_load_b8(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.rx) + (size_t)fr * a.rx_frame_bytes, 0, 0x7fffffff, 0x00020000), (unsigned)tid * 512u + 2u, 0, 2);
+        else b = a.rx[(size_t)fr * a.rx_frame_bytes + (size_t)tid * 512 + 2];
+    }
     {
+        // ALL of the workgroup's table loads are issued before the first is written to LDS: written as copy loops every iteration was
+        // load, wait, write -- five global round trips one after the other, 8 us in front of everything (tools/experiments_r06/
+        // dec_timeline.py, stamp set 1: this barrier stood at 8.4 us)
+        static_assert(GF_NT == 256 && 2 * FFT_NTAB == 384, "two loads per thread and table");
         uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
-        unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES);
-        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables);
-        for (int i = tid; i < 2 * FFT_NTAB; i += GF_NT) lt[i] = src[i];
-        for (int i = tid; i < 256 * 2; i += GF_NT) reinterpret_cast<uint4_t *>(tab)[i] = reinterpret_cast<const uint4_t *>(a.tab)[i];
-        if (tid < 64) reinterpret_cast<uint4_t *>(s->exp)[tid] = reinterpret_cast<const uint4_t *>(a.explog)[tid];
+        uint4_t *tab = reinterpret_cast<uint4_t *>(ldsraw + FFT_TAB_BYTES);
+        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables), *mt = reinterpret_cast<const uint4_t *>(a.tab);
+        const uint4_t z = {0u, 0u, 0u, 0u};
+        const uint4_t f0 = src[tid], f1 = tid < 128 ? src[256 + tid] : z;
+        const uint4_t m0 = mt[tid], m1 = mt[256 + tid];
+        const uint4_t el = tid < 64 ? reinterpret_cast<const uint4_t *>(a.explog)[tid] : z;
+        lt[tid] = f0;
+        if (tid < 128) lt[256 + tid] = f1;
+        tab[tid] = m0; tab[256 + tid] = m1;
+        if (tid < 64) reinterpret_cast<uint4_t *>(s->exp)[tid] = el;
     }
     s->cnt[tid] = 0;
     if (tid < 4 * DEC128_MAXN) s->lpx[tid] = 0; // (lpx, lqx, lpy, lqy: consecutive)
     __syncthreads();
+    PLAN_STAMP(1);
     if (tid < K) atomicAdd(&s->cnt[b], 1);
     __syncthreads();
+    PLAN_STAMP(2);
     const int wv = tid >> 6, ln = tid & 63;
     const bool is_rec = b >= K;
     unsigned long long br = 0ull, bm = 0ull;
@@ -94,6 +120,7 @@ __device__ __forceinline__ void dec128_plan(const Dec128Args &a, int fr, Dec128P
     }
     if (tid == 0) { pl->n = ok ? N : 0; pl->m1 = (ok && N == 1) ? 1 : 0; pl->maxrow = 0; pl->pad = (!ok && nmiss > 0) ? 1 : 0; if (ok && N == 1) pl->minv[0] = 1; }
     __syncthreads();
+    PLAN_STAMP(3);
     if (tid < K) {
         if (b < K) pl->inv[b] = (int16_t)tid; // (a repeated original: any copy)
         else if (ok) { pl->rowidx[b - K] = (uint8_t)rrank; pl->rpos[rrank] = (uint8_t)tid; atomicMax(&pl->maxrow, b - K); }
@@ -118,25 +145,46 @@ __device__ __forceinline__ void dec128_plan(const Dec128Args &a, int fr, Dec128P
             a.srcmap[(size_t)fr * 128u + tid] = code;
         }
     }
-    if (!(ok && N >= 2)) { __syncthreads(); return; } // (workgroup-uniform)
+    PLAN_STAMP(4);
+    __syncthreads();
+}
+
+// ... second part, for frames with N >= 2 (pl->n; workgroup-uniform): the N x N inverse.  Called by all four waves BEHIND the issue of their
+// 64 data loads (round 6): nothing in here touches what the loads return, the barriers wait for LDS only, so these ~2.4 us of LDS
+// latency chains run while the received blocks are on their way instead of in front of them.
+__device__ __forceinline__ void dec128_plan_inverse(Dec128Plan *pl, Dec128Scratch *s, int N)
+{
+    constexpr int K = 128;
+    const int tid = threadIdx.x;
     // Minv[t][i] = PX_i PY_t / ((x_i ^ y_t) QX_i QY_t (y_t ^ 128)), PX_i = prod_k (x_i ^ y_k), PY_t = prod_k (x_k ^ y_t), QX_i = prod_{k != i}
     // (x_i ^ x_k), QY_t = prod_{k != t} (y_t ^ y_k) (gf_decode_plan_kernel's closed form of the Cauchy inverse): the four logarithm
     // sums per index as LDS atomics over the N x N pairs -- a pair per thread instead of a serial N-step loop on N threads
+    // (every sum is filed under v = the thread's lane mod 32 -- two lanes per address in a wave's atomic; filed under u, as the first
+    // version had three of the four, all 32 lanes of a half wave met in one address: ~600 clocks per atomic, 4.3 us for this loop.
+    // PX_i: the pair (u, v) contributes log(x_v ^ y_u) to i = v; QX and QY are symmetric in their pair.)  A thread's four pairs share
+    // v: their terms are summed in registers, one atomic per sum.
+    {
+        const int v = tid & (DEC128_MAXN - 1);
+        int spx = 0, spy = 0, sqx = 0, sqy = 0;
+        if (v < N) {
+            const int xv = s->x[v], yv = s->y[v];
 #pragma unroll
-    for (int e = tid; e < DEC128_MAXN * DEC128_MAXN; e += GF_NT) {
-        const int u = e >> 5, v = e & (DEC128_MAXN - 1);
-        if (u < N && v < N) {
-            const int xu = s->x[u], yu = s->y[u], xv = s->x[v], yv = s->y[v];
-            const int lxy = s->log[xu ^ yv];
-            atomicAdd(&s->lpx[u], lxy);
-            atomicAdd(&s->lpy[v], lxy);
-            if (u != v) {
-                atomicAdd(&s->lqx[u], (int)s->log[xu ^ xv]);
-                atomicAdd(&s->lqy[u], (int)s->log[yu ^ yv]);
+            for (int u = tid >> 5; u < DEC128_MAXN; u += GF_NT / DEC128_MAXN) {
+                if (u < N) {
+                    const int xu = s->x[u], yu = s->y[u];
+                    spy += (int)s->log[xu ^ yv];
+                    spx += (int)s->log[xv ^ yu];
+                    if (u != v) { sqx += (int)s->log[xu ^ xv]; sqy += (int)s->log[yu ^ yv]; }
+                }
             }
+            atomicAdd(&s->lpx[v], spx);
+            atomicAdd(&s->lpy[v], spy);
+            atomicAdd(&s->lqx[v], sqx);
+            atomicAdd(&s->lqy[v], sqy);
         }
     }
     __syncthreads();
+    PLAN_STAMP(5);
 #pragma unroll
     for (int e = tid; e < DEC128_MAXN * DEC128_MAXN; e += GF_NT) {
         const int t = e >> 5, i = e & (DEC128_MAXN - 1);
@@ -148,25 +196,39 @@ __device__ __forceinline__ void dec128_plan(const Dec128Args &a, int fr, Dec128P
         }
     }
     __syncthreads();
+    PLAN_STAMP(6);
 }
 
 template <bool FUSED, bool NOCOPY = false> __device__ __forceinline__ void gf_decode128_fft_wg(const Dec128Args &a, int fr, unsigned char *ldsraw)
 {
     Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + FFT_TAB_BYTES + 256 * 32);
+    FFT_STAMP(0);
     if constexpr (FUSED) {
         dec128_plan(a, fr, pl, reinterpret_cast<Dec128Scratch *>(ldsraw + DEC128_FFT_LDS_BYTES), ldsraw); // (tables + plan; ends with a barrier)
     } else {
+        // (all loads first, then the LDS writes: dec128_plan)
+        static_assert(GF_NT == 256 && 2 * FFT_NTAB == 384 && DEC128_PLAN_BYTES / 16 <= GF_NT, "loads per thread");
         uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
-        unsigned *tab = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES); // all 256 constants: 8 dwords each
+        uint4_t *tab = reinterpret_cast<uint4_t *>(ldsraw + FFT_TAB_BYTES); // all 256 constants: 8 dwords each
         const int tid = threadIdx.x;
-        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables);
-        for (int i = tid; i < 2 * FFT_NTAB; i += GF_NT) lt[i] = src[i];
-        for (int i = tid; i < 256 * 2; i += GF_NT) reinterpret_cast<uint4_t *>(tab)[i] = reinterpret_cast<const uint4_t *>(a.tab)[i];
-        for (int i = tid; i < DEC128_PLAN_BYTES / 16; i += GF_NT)
-            reinterpret_cast<uint4_t *>(pl)[i] = reinterpret_cast<const uint4_t *>(a.plan + (size_t)fr * DEC128_PLAN_BYTES)[i];
+        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables), *mt = reinterpret_cast<const uint4_t *>(a.tab);
+        const uint4_t z = {0u, 0u, 0u, 0u};
+        const uint4_t f0 = src[tid], f1 = tid < 128 ? src[256 + tid] : z;
+        const uint4_t m0 = mt[tid], m1 = mt[256 + tid];
+        const uint4_t pr = tid < DEC128_PLAN_BYTES / 16 ? reinterpret_cast<const uint4_t *>(a.plan + (size_t)fr * DEC128_PLAN_BYTES)[tid] : z;
+        lt[tid] = f0;
+        if (tid < 128) lt[256 + tid] = f1;
+        tab[tid] = m0; tab[256 + tid] = m1;
+        if (tid < DEC128_PLAN_BYTES / 16) reinterpret_cast<uint4_t *>(pl)[tid] = pr;
         __syncthreads();
     }
-    fec_stagger_sleep(fr, a.stagger, a.stagger_div);
+    const int stagger_phase = fec_stagger_sleep(fr, a.stagger, a.stagger_div);
+    FFT_STAMP(1);
+    INV_STAMP(1);
+#ifdef FFT_STAMPS
+    if (FFT_STAMP_SET == 0 && (threadIdx.x & 63) == 0 && blockIdx.x < 2048) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_fft_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 6] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xfu) << 32) | ((unsigned long long)stagger_phase << 40); }
+#endif
+    (void)stagger_phase;
     // (the block half is a template parameter of everything behind this point, like the encoder's: gf_encode128_fft_wave)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wv >> 1) gf_decode128_fft_wave<1, FUSED, NOCOPY>(a, fr, ldsraw, wv & 1);
@@ -195,7 +257,7 @@ template <int HF, bool FUSED, bool NOCOPY> __device__ __forceinline__ void gf_de
     const __amdgpu_buffer_rsrc_t rpay = __builtin_amdgcn_make_buffer_rsrc(nocopy ? a.restored + (size_t)fr * (size_t)a.restored_rows * 508u : a.payload_out + (size_t)fr * a.payload_frame_bytes,
                                                                           0, 0x7fffffff, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    unsigned d[64], e[16];
+    unsigned d[64], e[16], rec[16];
     {
         const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
         const bool live = col < 127u;
@@ -216,8 +278,12 @@ template <int HF, bool FUSED, bool NOCOPY> __device__ __forceinline__ void gf_de
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
             const int pos = __builtin_amdgcn_readlane(invv, i); // position of original b0 + i in the received array, -1 = erased
-            const unsigned v = __builtin_amdgcn_raw_buffer_load_b32(rrx, lc4, (pos < 0 ? 0 : pos & 127) * 512, 0); // (erased: some block that exists)
-            d[i] = pos < 0 ? 0u : v;
+            // (erased: an offset beyond the descriptor's range -- the load returns zero; a select on the loaded value here would stand
+            // between the loads and the plan's second part and wait for the data)
+            d[i] = __builtin_amdgcn_raw_buffer_load_b32(rrx, pos < 0 ? OOB : lc4, (pos < 0 ? 0 : pos & 127) * 512, DEC_LOAD_AUX);
+        }
+        if constexpr (FUSED) {
+            if (N >= 2) dec128_plan_inverse(pl, reinterpret_cast<Dec128Scratch *>(ldsraw + DEC128_FFT_LDS_BYTES), N); // (uniform; barriers inside)
         }
         // the received originals go to their places (getSlotData's layout: blocks 1..127 back to back, block 0 apart) -- the first
         // 32 of the wave's blocks here, the other 32 between the two halves of the transform (fft_rows16's hook: they may still be
@@ -266,6 +332,15 @@ template <int HF, bool FUSED, bool NOCOPY> __device__ __forceinline__ void gf_de
 #pragma unroll
             for (int i = 32; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
             (xch0 + lane)[(32 + hf) * 64] = par;
+        }, [&]() __attribute__((always_inline)) {
+            // the received recovery rows among rows 16 hf .. 16 hf + 15, on their way while the exchange and the size-16 transform run
+            const unsigned ld4 = live ? lc4 : OOB;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ri = __builtin_amdgcn_readfirstlane((int)pl->rowidx[16 * hf + i]); // 255 = not received
+                const int rp = ri == 255 ? 0 : __builtin_amdgcn_readfirstlane((int)pl->rpos[ri & 31]) & 127; // (a row that did not arrive: block 0, not used)
+                rec[i] = __builtin_amdgcn_raw_buffer_load_b32(rrx, ld4, rp * 512, DEC_LOAD_AUX);
+            }
         });
     }
 
@@ -273,15 +348,7 @@ template <int HF, bool FUSED, bool NOCOPY> __device__ __forceinline__ void gf_de
     {
         // syndromes of the received recovery rows among rows 16 hf .. 16 hf + 15: recovery ^ (P ^ (r c / q) * value_r)
         const unsigned lane = fft_lane(), col = (unsigned)ch * 64u + lane;
-        const unsigned ld4 = col < 127u ? 4u * col : OOB;
         const unsigned P = (xch0 + lane)[32 * 64] ^ (xch0 + lane)[33 * 64];
-        unsigned rec[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int ri = __builtin_amdgcn_readfirstlane((int)pl->rowidx[16 * hf + i]); // 255 = not received
-            const int rp = ri == 255 ? 0 : __builtin_amdgcn_readfirstlane((int)pl->rpos[ri & 31]) & 127; // (a row that did not arrive: block 0, not used)
-            rec[i] = __builtin_amdgcn_raw_buffer_load_b32(rrx, ld4, rp * 512, 0);
-        }
         __syncthreads(); // (both waves are through with the exchange rows: the syndromes take their place)
         {
             FftTabs R;
@@ -301,6 +368,7 @@ template <int HF, bool FUSED, bool NOCOPY> __device__ __forceinline__ void gf_de
         }
         __syncthreads();
     }
+    FFT_STAMP(5);
 
     // erased originals = Minv x syndromes: this wave takes rows t = w + 4 u of its column half for w = hf and w = hf + 2 (up to 8 each);
     // a syndrome dword is split into its selector words once and multiplied by the constants of all the wave's rows.  Two
@@ -366,4 +434,5 @@ template <int HF, bool FUSED, bool NOCOPY> __device__ __forceinline__ void gf_de
             }
         }
     }
+    FFT_STAMP(7);
 }

@@ -32,6 +32,9 @@
 // 14 us each on 1024 SIMDs is a two-and-a-bit-round launch); 95 registers, 23.5 KB of LDS: four to five workgroups per CU.
 #pragma once
 
+#ifndef ENC_LOAD_AUX
+#define ENC_LOAD_AUX 0 // (buffer cache policy of the 64 data loads; 2 = nt: see gf_decode128_fft.h, DEC_LOAD_AUX.  The encoder's input was written by the launch in front of it)
+#endif
 constexpr int FFT_NTAB = 192;                       // gf256.h: CM256_FFT_TABLES
 constexpr int FFT_TAB_BYTES = FFT_NTAB * 32;        // the 32-byte records of gf_build_tables as they are: {Ta, Tb} 16 B, {Tc} 4 B, 12 B unused (ONE address register)
 // + per column half 32 x 64 dwords of exchange (e_lo down, rows 0..15 back up) and 2 x 64 of parity
@@ -40,6 +43,24 @@ constexpr int ENC128_FFT_LDS_BYTES = FFT_TAB_BYTES + 2 * FFT_XCH_DWORDS * 4;
 constexpr int FFT_MAX_ROWS = 32;
 #ifndef FFT_WAVES_PER_EU
 #define FFT_WAVES_PER_EU 4 // (the compiler's register budget: 128; the kernel takes 95, so five waves per SIMD are resident where the LDS allows)
+#endif
+
+#ifdef FFT_STAMPS
+// timeline experiment (tools/experiments_r05/fft_stamps.py, dec_stamps.py, tools/experiments_r06/stagger_rank.py): lane 0 of every wave of
+// the first 2048 workgroups leaves s_memrealtime (100 MHz) at up to eight points (+ HW_ID).  FFT_STAMP_SET picks which points: 0 = the
+// phases of the kernel, 1 = inside the decoder's plan, 2 = inside the size-64 inverse transform; points 0 (start) and 7 (end) in every set
+#ifndef FFT_STAMP_SET
+#define FFT_STAMP_SET 0
+#endif
+__device__ unsigned long long g_fft_stamps[8192 * 8];
+#define FFT_STAMP_RAW(k) do { if (blockIdx.x < 2048 && (threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_fft_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
+#define FFT_STAMP(k) do { if (FFT_STAMP_SET == 0 || (k) == 0 || (k) == 7) FFT_STAMP_RAW(k); } while (0)
+#define PLAN_STAMP(k) do { if (FFT_STAMP_SET == 1) FFT_STAMP_RAW(k); } while (0)
+#define INV_STAMP(k) do { if (FFT_STAMP_SET == 2) FFT_STAMP_RAW(k); } while (0)
+#else
+#define FFT_STAMP(k) do { } while (0)
+#define PLAN_STAMP(k) do { } while (0)
+#define INV_STAMP(k) do { } while (0)
 #endif
 
 // The multiplier tables travel through two or three register sets: while block n is multiplied, the table of block n + 1 (inverse
@@ -115,7 +136,7 @@ template <int HF, class MID> __device__ __forceinline__ void fft_inverse64_fold(
     fft_issue<1, fft_inv_table(1)>(R, lh);
     fft_for<63>([&](auto nc) __attribute__((always_inline)) {
         constexpr int n = decltype(nc)::value, k = fft_inv_block(n).k, j = fft_inv_block(n).j, h = 1 << k, blk = j * 2 * h, P = n % 3;
-        if constexpr (n == 31) mid();
+        if constexpr (n == 31) { INV_STAMP(3); mid(); INV_STAMP(4); }
         fft_wait_ahead<P>(R); // (position n + 1's table -- t5 behind the last block -- is on its way)
         if constexpr (n + 2 < 63) fft_issue<(n + 2) % 3, fft_inv_table(n + 2)>(R, lh);
         else if constexpr (n + 2 == 63) fft_issue<(n + 2) % 3, 126>(R, la); // t5
@@ -127,9 +148,11 @@ template <int HF, class MID> __device__ __forceinline__ void fft_inverse64_fold(
             for (int i = 0; i < h; ++i) fft_muladd<P>(d[blk + i], d[blk + h + i], R);
         }
     });
+    INV_STAMP(5);
     fft_wait<63 % 3>(R);
 #pragma unroll
     for (int i = 0; i < 32; ++i) fft_muladd<63 % 3>(d[i], d[32 + i], R);
+    INV_STAMP(6);
 }
 
 // rows 16 hh .. 16 hh + 15 of the size-32 transform on 128 + V5 behind its first stage: stages 3..0 on 16 values; the tables of
@@ -158,21 +181,21 @@ __device__ __forceinline__ void fft_forward16(unsigned (&e)[16], int hh, unsigne
     });
 }
 
-#ifdef FFT_STAMPS
-// timeline experiment (tools/experiments_r05/fft_stamps.py): lane 0 of every wave of the first 2048 workgroups leaves s_memrealtime
-// (100 MHz) at six points + HW_ID
-__device__ unsigned long long g_fft_stamps[8192 * 8];
-#define FFT_STAMP(k) do { if (blockIdx.x < 2048 && (threadIdx.x & 63) == 0) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_fft_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_; } } while (0)
-#else
-#define FFT_STAMP(k) do { } while (0)
-#endif
-
 // the workgroup's tables: global (32-byte records) -> LDS {16 B} + {4 B} arrays.  All threads; a barrier follows.
 __device__ __forceinline__ void fft_fill_tables(const Enc128Args &a, unsigned char *ldsraw)
 {
-    uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
+    // (both loads of a thread are issued before the first is written: as a copy loop the two iterations were load, wait, write twice --
+    // two global round trips in front of the workgroup's data loads.  In asm: written in C the same statements moved the register
+    // allocation of the whole kernel from 96 to 127 registers, i.e. from five to four workgroups per CU)
+    static_assert(GF_NT == 256 && 2 * FFT_NTAB == 384, "two loads per thread");
+    const unsigned tid = threadIdx.x, i1 = tid < 128u ? 256u + tid : tid; // (threads 128..255: their own entry again)
     const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables);
-    for (int i = threadIdx.x; i < 2 * FFT_NTAB; i += GF_NT) lt[i] = src[i];
+    uint4_t f0, f1;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(f0), "=&v"(f1) : "v"(src + tid), "v"(src + i1) : "memory");
+    uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
+    lt[tid] = f0;
+    lt[i1] = f1;
     __syncthreads();
 }
 
@@ -183,11 +206,15 @@ __device__ __forceinline__ void fft_fill_tables(const Enc128Args &a, unsigned ch
 // HF is a template parameter: the two block halves run different code (the first half's stages begin with a block whose constant
 // is zero -- 63 of its 224 multiplications -- and the exchange is not symmetric); as a run-time value the skipped blocks became
 // branches inside the network and the register allocator spilled at every join.
-template <int HF, class MID> __device__ __forceinline__ void fft_rows16(unsigned (&d)[64], unsigned (&e)[16], unsigned la, unsigned *xch0, MID &&mid)
+// post(): called behind the fold, in front of the exchange -- the decoder issues its recovery-row loads there (the second half of d[]
+// is free from here on): they used to go out behind the exchange, right in front of their use -- a global round trip on the path.
+template <int HF, class MID, class POST> __device__ __forceinline__ void fft_rows16(unsigned (&d)[64], unsigned (&e)[16], unsigned la, unsigned *xch0, MID &&mid, POST &&post)
 {
     constexpr int hf = HF;
     FFT_STAMP(2);
+    INV_STAMP(2);
     fft_inverse64_fold<HF>(d, la + (unsigned)(hf * 63 * 32), la, mid);
+    post();
     FFT_STAMP(3);
     unsigned *const xch = xch0 + fft_lane();
     if constexpr (hf == 0) {
@@ -290,7 +317,7 @@ template <int HF> __device__ __forceinline__ void gf_encode128_fft_wave(const En
         d[0] = hf ? vb : (own0 ? blk0 : v0);
     }
 #pragma unroll
-    for (int i = 1; i < 64; ++i) d[i] = __builtin_amdgcn_raw_buffer_load_b32(rl, lc4, (b0 + i) * pitch, 0);
+    for (int i = 1; i < 64; ++i) d[i] = __builtin_amdgcn_raw_buffer_load_b32(rl, lc4, (b0 + i) * pitch, ENC_LOAD_AUX);
     if (strad) {
         // the straddling frame went through the sequence above as a frame in memory; now every lane replaces what the stream holds
         // (in place, sixteen blocks at a time: a second sequence DEFINING the 64 registers is what the allocator could not join)
@@ -325,7 +352,7 @@ template <int HF> __device__ __forceinline__ void gf_encode128_fft_wave(const En
 #pragma unroll
         for (int i = 32; i < 64; i += 2) par = x3(par, d[i], d[i + 1]);
         (xch0 + fft_lane())[(32 + hf) * 64] = par;
-    });
+    }, []() __attribute__((always_inline)) {});
     // rows 16 hf + i
     {
         FftTabs R;

@@ -219,7 +219,7 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
     else if (k == "mfma_ring" && isnum && (num == 3 || num == 4)) c->opt.mfma_ring = (int)num;
     else if (k == "tx_overlap" && isnum && num <= 1) c->opt.tx_overlap = (int)num;
     else if (k == "fec_stagger" && isnum && num <= 64) c->opt.fec_stagger = (int)num;
-    else if (k == "fec_stagger_mod" && isnum && num <= 16) c->opt.fec_stagger_mod = (int)num;
+    else if (k == "fec_stagger_mod" && isnum && num <= 116) c->opt.fec_stagger_mod = (int)num;
     else if (k == "tx_gather" && isnum && num <= 1) c->opt.tx_gather = (int)num;
     else if (k == "dec_plan") {
         if (v == "fused") c->opt.dec_fused_plan = 1;

@@ -282,12 +282,33 @@ struct Enc128Args {
 };
 // the sleep in front of a workgroup's loads (Enc128Args::stagger, DecodeBuffers::stagger)
 #if defined(__HIPCC__)
-__device__ __forceinline__ void fec_stagger_sleep(int unit, int stagger, int stagger_div)
+// arrival counters per CU (key = XCC_ID, SE / SH / CU of HW_ID), never reset: the workgroups a CU receives one after the other get
+// consecutive ranks whatever the dispatcher's dealing is (stagger_div <= -100)
+static __device__ unsigned g_fec_cu_rank[4096];
+__device__ __forceinline__ int fec_stagger_phase(int unit, int stagger_div)
 {
-    if (stagger <= 0 || stagger_div == 0) return;
+    if (stagger_div <= -100) {
+        __shared__ int s_phase;
+        if (threadIdx.x == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned key = ((xcc & 0xfu) << 8) | ((hw >> 8) & 0xffu);
+            s_phase = (int)(atomicAdd(&g_fec_cu_rank[key], 1u) % (unsigned)(-stagger_div - 100));
+        }
+        __syncthreads();
+        return __builtin_amdgcn_readfirstlane(s_phase);
+    }
     // stagger_div > 0: phase = the resident round (unit / CUs); < 0: phase = unit mod -stagger_div (consecutive workgroups on one CU)
-    const int n = (stagger_div > 0 ? unit / stagger_div : unit % -stagger_div) * stagger; // (workgroup-uniform)
+    return stagger_div > 0 ? unit / stagger_div : unit % -stagger_div;
+}
+__device__ __forceinline__ int fec_stagger_sleep(int unit, int stagger, int stagger_div)
+{
+    if (stagger <= 0 || stagger_div == 0) return 0;
+    const int ph = fec_stagger_phase(unit, stagger_div); // (workgroup-uniform)
+    const int n = ph * stagger;
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+    return ph;
 }
 #endif
 // smallest number of recovery blocks the structured 128-original encoder is used for (below: the generic matrix kernel)
