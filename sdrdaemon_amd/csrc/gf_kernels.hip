@@ -288,7 +288,11 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
     const int f = blockIdx.x, p = threadIdx.x;
     for (int i = p; i < 512; i += K) s_exp[i] = a.explog[i];
     for (int i = p; i < 256; i += K) s_log[i] = reinterpret_cast<const uint16_t *>(a.explog + 512)[i];
-    const int b = a.indices ? a.indices[(size_t)f * K + p] : a.rx[(size_t)f * a.rx_frame_bytes + (size_t)p * 512 + 2];
+    // (the header bytes non-temporal: with the default policy their 128 lines per frame allocate in the caches and evict dirty lines of
+    // the launch in front -- gf_decode128_fft.h, DEC_HDR_NT: 8.1 against 4.4 us for this round trip)
+    const int b = a.indices ? a.indices[(size_t)f * K + p]
+                            : __builtin_amdgcn_raw_buffer_load_b8(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.rx) + (size_t)f * a.rx_frame_bytes, 0, 0x7fffffff, 0x00020000),
+                                                                  (unsigned)p * 512u + 2u, 0, 2);
     s_idx[p] = (uint8_t)b;
     s_cnt[p] = 0;
     if (p == 0) s_bad = 0;

@@ -22,6 +22,7 @@ buf = (ctypes.c_ulonglong * (8192 * 8))()
 lib.sdrhip_debug_fft_stamps.argtypes = [ctypes.c_void_p]
 assert lib.sdrhip_debug_fft_stamps(buf) == 0
 st = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
+st = np.concatenate([st, (np.arange(8192) & 3)[:, None]], axis=1)  # column 8: the wave's index in its workgroup (ch = w & 1, hf = w >> 1)
 st = st[st[:, 0] > 0]
 st = st[st[:, 0] > st[:, 0].max() - 100000]  # the last launch only (1 ms)
 t0 = st[:, 0].min()
@@ -35,3 +36,14 @@ hw = st[:, 6]
 cu = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4) | (((hw >> 16) & 0x1) << 7)  # cu_id, se_id, sh_id (within the XCC)
 late = st[:, 0] - t0 > 500
 print("waves that started > 5 us after the first: %d; their starts (us): %s" % (late.sum(), np.sort(np.unique(((st[late, 0] - t0) * 0.01).round(0)))[:20]))
+
+# which SIMD does wave w of a workgroup run on?  (hf = 1 waves carry 320 constant multiplications, hf = 0 waves 209)
+simd = (hw >> 4) & 3
+tab = np.zeros((4, 4), dtype=int)
+for w, sd in zip(st[:, 8], simd):
+    tab[int(w), int(sd)] += 1
+print("wave index in the workgroup (rows) x SIMD (columns):")
+print(tab)
+for w in range(4):
+    m = st[:, 8] == w
+    print("wave %d (ch %d, hf %d): inverse64 + fold mean %.2f us, end of wave p50 %.2f p90 %.2f us" % (w, w & 1, w >> 1, ((st[m, 3] - st[m, 2]) * 0.01).mean(), np.percentile((st[m, 5] - t0) * 0.01, 50), np.percentile((st[m, 5] - t0) * 0.01, 90)))
