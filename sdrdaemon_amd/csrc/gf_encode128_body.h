@@ -172,15 +172,30 @@ __device__ __forceinline__ void gf_encode128_wg(const Enc128Args &a, int bx, uns
     unsigned *rt4 = reinterpret_cast<unsigned *>(ldsraw + 8 * KLEAVES * 20 + 128 * 16);
     unsigned (*ysum)[64] = reinterpret_cast<unsigned (*)[64]>(ldsraw + 8 * KLEAVES * 20 + 128 * 20); // reduced convolution (32 rows) + parity (row 32)
     const int tid = threadIdx.x;
-    for (int i = tid; i < 8 * KLEAVES; i += GF_NT) { // (32-byte table records: whole 16-byte loads)
-        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.leaf_tables) + (size_t)i * 2;
-        lt16[i] = src[0];
-        lt4[i] = reinterpret_cast<const unsigned *>(src + 1)[0];
-    }
-    if (tid < 128) {
-        const uint4_t *src = reinterpret_cast<const uint4_t *>(a.tab) + (size_t)tid * 2;
-        rt16[tid] = src[0];
-        rt4[tid] = reinterpret_cast<const unsigned *>(src + 1)[0];
+    {
+        // (32-byte table records: whole 16-byte loads, ALL of a thread's loads before its first LDS write -- written as a copy loop
+        // hipcc made every iteration load, wait, write: three global round trips one after the other)
+        static_assert(GF_NT == 256 && 8 * KLEAVES <= 3 * GF_NT, "three records per thread");
+        uint4_t l16[3], r16;
+        unsigned l4[3], r4;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = tid + k * GF_NT;
+            const uint4_t *src = reinterpret_cast<const uint4_t *>(a.leaf_tables) + (size_t)(i < 8 * KLEAVES ? i : 0) * 2;
+            l16[k] = src[0];
+            l4[k] = reinterpret_cast<const unsigned *>(src + 1)[0];
+        }
+        {
+            const uint4_t *src = reinterpret_cast<const uint4_t *>(a.tab) + (size_t)(tid & 127) * 2;
+            r16 = src[0];
+            r4 = reinterpret_cast<const unsigned *>(src + 1)[0];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = tid + k * GF_NT;
+            if (i < 8 * KLEAVES) { lt16[i] = l16[k]; lt4[i] = l4[k]; }
+        }
+        if (tid < 128) { rt16[tid] = r16; rt4[tid] = r4; }
     }
     for (int i = tid; i < 33 * 64; i += GF_NT) (&ysum[0][0])[i] = 0;
     __syncthreads();

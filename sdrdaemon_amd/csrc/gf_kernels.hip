@@ -276,8 +276,9 @@ static_assert(sizeof(Dec128Plan) % 16 == 0 && sizeof(Dec128Plan) == DECODE_PLAN2
 __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
 {
     constexpr int K = 128;
-    __shared__ uint8_t s_exp[512];
-    __shared__ uint16_t s_log[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_explog[1024]; // exp[512], then log[256] (uint16): gf_explog as it is
+    uint8_t *const s_exp = s_explog;
+    uint16_t *const s_log = reinterpret_cast<uint16_t *>(s_explog + 512);
     __shared__ uint8_t s_idx[K], s_x[K], s_y[K], s_rank[K], s_rpos[K];
     __shared__ int s_cnt[K];
     __shared__ int s_lpx[K], s_lqx[K], s_lpy[K], s_lqy[K];
@@ -286,13 +287,16 @@ __global__ __launch_bounds__(128) void gf_decode_plan_kernel(DecPlanArgs a)
     __shared__ int s_bad;
     __shared__ unsigned long long s_mask[2][3];
     const int f = blockIdx.x, p = threadIdx.x;
-    for (int i = p; i < 512; i += K) s_exp[i] = a.explog[i];
-    for (int i = p; i < 256; i += K) s_log[i] = reinterpret_cast<const uint16_t *>(a.explog + 512)[i];
+    // (one 16-byte load per thread, issued with the header byte: as two copy loops of bytes / halfwords the table arrived in six
+    // global round trips one after the other)
+    uint4_t el = {0u, 0u, 0u, 0u};
+    if (p < 64) el = reinterpret_cast<const uint4_t *>(a.explog)[p];
     // (the header bytes non-temporal: with the default policy their 128 lines per frame allocate in the caches and evict dirty lines of
     // the launch in front -- gf_decode128_fft.h, DEC_HDR_NT: 8.1 against 4.4 us for this round trip)
     const int b = a.indices ? a.indices[(size_t)f * K + p]
                             : __builtin_amdgcn_raw_buffer_load_b8(__builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.rx) + (size_t)f * a.rx_frame_bytes, 0, 0x7fffffff, 0x00020000),
                                                                   (unsigned)p * 512u + 2u, 0, 2);
+    if (p < 64) reinterpret_cast<uint4_t *>(s_explog)[p] = el;
     s_idx[p] = (uint8_t)b;
     s_cnt[p] = 0;
     if (p == 0) s_bad = 0;
@@ -565,7 +569,9 @@ template <bool OWN> __device__ __forceinline__ void gf_decode128_wg(const Dec128
     Dec128Plan *pl = reinterpret_cast<Dec128Plan *>(ldsraw + 8 * KLEAVES * 20 + 256 * 32 + 33 * 64 * 4 + DEC128_MAXN * 64 * 4);
     const int tid = threadIdx.x;
     const int fr = bx >> 1;
-    // (tables and plan records are 32- / 16-byte aligned: whole 16-byte loads, all of them in flight before the first LDS store)
+    // (tables and plan records are 32- / 16-byte aligned: whole 16-byte loads)
+    // (copy loops: hipcc compiles every iteration as load, wait, write -- left so in this fallback kernel: with all loads first the
+    // FFT decoder's non-fused kernel, which holds this walk as its in-launch fallback, spills ten registers more)
     for (int i = tid; i < 8 * KLEAVES; i += GF_NT) {
         const uint4_t *src = reinterpret_cast<const uint4_t *>(a.leaf_tables) + (size_t)i * 2;
         lt16[i] = src[0];

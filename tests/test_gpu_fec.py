@@ -348,11 +348,21 @@ def test_fused_plan_equals_the_planning_kernel_on_hostile_batches(ctx, oracle, s
                 ctx.set_option("dec_path", "syndrome")
         idx = np.ascontiguousarray(rx[:, :, 2])
         outs["fused-indices"] = sd.fec_decode_frames(ctx, rx, indices=idx, want_block0=True)
+        # the staggered start in both phase rules (experiment options: a sleep in front of the loads, the arrival-rank rule with a
+        # barrier of its own): same bytes
+        for mod in (104, 3):
+            ctx.set_option("fec_stagger", 2)
+            ctx.set_option("fec_stagger_mod", mod)
+            try:
+                outs["fused-stagger-%d" % mod] = sd.fec_decode_frames(ctx, rx, want_block0=True)
+            finally:
+                ctx.set_option("fec_stagger", 0)
+                ctx.set_option("fec_stagger_mod", 0)
     finally:
         ctx.set_option("dec_max_rows", 128)
         ctx.set_option("dec_strict", 0)
     assert counts["fused"] == counts["kernel"] == counts["dense"] == F // 9
-    for name in ("kernel", "dense", "fused-indices"):
+    for name in ("kernel", "dense", "fused-indices", "fused-stagger-104", "fused-stagger-3"):
         for k in (0, 1):
             bad = [f for f in range(F) if not np.array_equal(outs["fused"][k][f], outs[name][k][f])]
             assert not bad, (name, ("payload", "block0")[k], bad, [f % 9 for f in bad])
