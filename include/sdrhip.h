@@ -83,7 +83,7 @@ int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
  * fused | kernel (batched decode with dec_max_rows <= 32 on the FFT decoder: each frame's plan is made by the decoder's own
  * workgroup, the default, or by the planning kernel in a launch of its own), "rx_window" = 0 | 1..8 (frame window of the Rx pipe in
  * calls; 0 = the default: 2, pipelined pipes 4), "fec_stagger" / "fec_stagger_mod" (experiment: staggered start of the FFT encoder's /
- * decoder's workgroups, default off), "ktime_stride" = 1..1024 / "ktime_stride_class" = "<class>:<stride>" (the kernel-class timers
+ * decoder's workgroups, default off; mod 0: phase = resident round, 1..16: workgroup mod m, 100 + m: the workgroup's arrival rank on its CU mod m), "ktime_stride" = 1..1024 / "ktime_stride_class" = "<class>:<stride>" (the kernel-class timers
  * of sdrhip_ctx_kernel_timing bracket every n-th launch, of all classes / of one).  Every setting computes the same bytes.  One knob is a promise, not a path: "dec_max_rows" = 1..128 (default 128), the most recovery
  * blocks a received frame can carry (the sender's fecblk, known from the meta block; a collector that counted the recovery blocks
  * of a batch -- adapters/UDPSourceFEC.h -- passes that count); <= 32 makes the batched decode ONE launch (the plan inside the

@@ -457,7 +457,15 @@ template <int L, bool GATHER = false> __device__ __forceinline__ void interp_wav
         int32_t *stn = a.state_next + (size_t)stream * INT_STATE_WORDS;
         wave_sync();
         wstate_store<G>(lds, lane, stn);
-        for (int i = NS * 2 * INT_HIST + lane; i < INT_STAGES * 2 * INT_HIST; i += WNT) stn[i] = stc[i];
+        // the stages this ratio does not use travel as they are (loads first, then the stores: as a copy loop every iteration was a
+        // global round trip of its own, at the end of the wave that ends the launch)
+        constexpr int REST = (INT_STAGES - NS) * 2 * INT_HIST;
+        static_assert(REST % WNT == 0, "whole waves");
+        int32_t keep[REST / WNT > 0 ? REST / WNT : 1];
+#pragma unroll
+        for (int k = 0; k < REST / WNT; ++k) keep[k] = stc[NS * 2 * INT_HIST + k * WNT + lane];
+#pragma unroll
+        for (int k = 0; k < REST / WNT; ++k) stn[NS * 2 * INT_HIST + k * WNT + lane] = keep[k];
     }
 }
 

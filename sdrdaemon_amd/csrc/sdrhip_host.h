@@ -148,7 +148,7 @@ struct CtxOptions {
     int tx_overlap = 1;                    // pipelined Tx pipe: 1 = decode of this batch on the second stream beside the interpolator of the previous one, 0 = one stream
     int enc_fft = 1;                       // structured 128-original encoder, rows <= 32: additive FFT (1) or the Karatsuba XOR-convolution walk (0)
     int enc_min_rows = 1;                  // ... the FFT from this many recovery blocks on (the generic matrix kernel below)
-    int fec_stagger_mod = 0;               // 0: phase = resident round (workgroup / CUs); m > 0: phase = workgroup mod m (experiment)
+    int fec_stagger_mod = 0;               // 0: phase = resident round (workgroup / CUs); 1..16: phase = workgroup mod m; 100 + m: arrival rank on the CU mod m (experiment)
     int fec_stagger = 0;                   // staggered start of the FFT encoder's / decoder's workgroups, units of 1024 clocks per resident round (0 = off)
     // Tx pipe without the decoder's copy (built in round 6): immediate mode on K5w with the fused-plan decoder, the
     // interpolator gathers the received originals through the decoder's position map.  OFF by default: the decoder gets 11 us
