@@ -357,6 +357,29 @@ template <int N> __device__ __forceinline__ void mf_wait_vm()
     if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
+#ifdef MF_STAMPS
+// timeline experiment (tools/experiments_r06/k1m_timeline.py): lane 0 of every matrix-core wave leaves s_memrealtime (100 MHz) at eight
+// points -- 0 start, 1 constants + ring issued, 2 first group landed, 3 .. 6 = 1, 25, 50, 75 % of the periods done, 7 end -- and HW_ID
+__device__ unsigned long long g_mf_stamps[4096 * 10];
+__device__ __forceinline__ void mf_stamp(int gw, int k)
+{
+    if ((threadIdx.x & 63) == 0 && gw < 4096) {
+        unsigned long long t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        g_mf_stamps[gw * 10 + k] = t;
+        if (k == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_mf_stamps[gw * 10 + 8] = ((unsigned long long)(xcc & 0xfu) << 32) | hw;
+        }
+    }
+}
+#define MF_STAMP(gw, k) mf_stamp(gw, k)
+#else
+#define MF_STAMP(gw, k) do { } while (0)
+#endif
+
 // (A loader-wave variant -- a fifth wave per workgroup issues all DMAs, the compute waves meet it at one s_barrier per group -- was
 // measured slower, 0.244-0.252 ms against 0.232-0.238 ms with the DMAs in the compute waves: tools/experiments_r03/
 // decim_mfma_experiments.patch, MF_LOADER.)
@@ -369,7 +392,7 @@ template <int N> __device__ __forceinline__ void mf_wait_vm()
 // behind its last DMA the wave has issued the NG - 3 + 1 full groups in between and 7 DMAs of the current issue group.
 template <int NS, int NG, class OC>
 __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st, const MfConst &k, OC &oc, MfFront &fr, unsigned lds_addr,
-                                            const char *wbase, size_t S, int nper, int WP, int lane, int p, int comp, int q)
+                                            const char *wbase, size_t S, int nper, int WP, int lane, int p, int comp, int q, int gw)
 {
     constexpr int P = mf_period<NS>();
     static_assert(P == 32, "four groups of 8 steps per period");
@@ -406,9 +429,17 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
             mf_dma_issue<i % 8>(rs[i / 8], v0 + 1024u * (unsigned)(i / 8), sb[i % 8]);
         });
     }
+    MF_STAMP(gw, 1);
     mf_wait_vm<8 * (LA - 1)>(); // group 0 has landed
     uint4_t r = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lr[0]);
+    MF_STAMP(gw, 2);
     for (int per = 0; per < nper; ++per) {
+#ifdef MF_STAMPS
+        if (per == 1) MF_STAMP(gw, 3);
+        if (per == nper / 4) MF_STAMP(gw, 4);
+        if (per == nper / 2) MF_STAMP(gw, 5);
+        if (per == 3 * nper / 4) MF_STAMP(gw, 6);
+#endif
         oc.store = per >= WP;
         mf_static_for<P>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -528,7 +559,7 @@ template <int NS, int NG = 0, bool FR = false> __device__ __forceinline__ void m
     fr.sel_lo = comp ? 0x05040100u : 0x01000504u; fr.sel_hi = comp ? 0x07060302u : 0x03020706u;
     fr.ev_lo = 0u; fr.ev_hi = 0u;
     if constexpr (NG != 0 && mf_dma_applies(NS)) {
-        mf_loop_dma<NS, NG>(a, st, k, oc, fr, lds_addr, wbase, S, nper, WP, lane, p, comp, q);
+        mf_loop_dma<NS, NG>(a, st, k, oc, fr, lds_addr, wbase, S, nper, WP, lane, p, comp, q, gw);
         return;
     }
     uint4_t ld[D];
@@ -597,8 +628,15 @@ template <int L, bool PACK16, int NG, bool FR> __global__ __launch_bounds__(mf_b
     }
     const int gw = __builtin_amdgcn_readfirstlane(bx * 4 + (int)(threadIdx.x >> 6));
     if (gw >= a.nstreams * a.mf_wps) return;
+    MF_STAMP(gw, 0);
     mf_wave<L, NG, FR>(a, gw, (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds);
+    MF_STAMP(gw, 7);
 }
+#ifdef MF_STAMPS
+} // namespace
+extern "C" int sdrhip_debug_mf_stamps(unsigned long long *dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_mf_stamps), sizeof(g_mf_stamps)); }
+namespace {
+#endif
 
 // ---- fused Rx launch: the decimator of THIS call and the CM256 encoder of the frames the PREVIOUS call completed, in one grid.
 // The matrix-core waves run one per SIMD and leave ~40 % of their SIMD's issue slots empty (memory waits, dependent issue);
