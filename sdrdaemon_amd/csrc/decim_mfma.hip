@@ -396,7 +396,7 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
 {
     constexpr int P = mf_period<NS>();
     static_assert(P == 32, "four groups of 8 steps per period");
-    static_assert(NG == 3 || NG == 4, "ring depth");
+    static_assert(NG == 2 || NG == 3 || NG == 4, "ring depth");
     constexpr int LA = NG - 1; // groups the DMAs run ahead
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const unsigned ring = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_addr + (unsigned)wv * (unsigned)mf_wave_ring(NG)));
@@ -446,7 +446,8 @@ __device__ __forceinline__ void mf_loop_dma(const DecimArgs &a, MfState<NS> &st,
             constexpr int i1 = i + 1; // the step read ahead; i1 = 32: step 0 of the next period = group 4 of this one
             // (MF_DMA_BURST = B: the 8 DMAs of a group go out B per step in its first 8 / B steps instead of one per step -- the
             // shallow ring's worst-case lead is then 8 LA steps instead of 8 LA - 7)
-            constexpr int B = MF_DMA_BURST;
+            // (NG = 2, the two-waves-per-SIMD experiment: one group ahead, so the whole next group goes out at the first step of this one)
+            constexpr int B = NG == 2 ? 8 : MF_DMA_BURST;
             if constexpr (i1 % 8 == 0) mf_wait_vm<(B == 1 ? 8 * (LA - 2) + 7 : 8 * (LA - 1))>(); // the next group has landed
             const uint4_t rn = *reinterpret_cast<const __attribute__((address_space(3))) uint4_t *>(lr[(i1 / 8) % NG] + 128 * (i1 % 8));
             constexpr int g = i / 8, d = i % 8;
@@ -592,7 +593,7 @@ template <int NS, int NG = 0, bool FR = false> __device__ __forceinline__ void m
 // workgroups (head + tail pieces of every stream)
 __host__ __device__ constexpr int mf_block_threads(int) { return NT; }
 
-template <int L, bool PACK16, int NG, bool FR> __global__ __launch_bounds__(mf_block_threads(L), mf_dma_applies(L) ? 1 : MF_WAVES) void decim_mfma_kernel(DecimArgs a)
+template <int L, bool PACK16, int NG, bool FR> __global__ __launch_bounds__(mf_block_threads(L), mf_dma_applies(L) && NG != 2 ? 1 : MF_WAVES) void decim_mfma_kernel(DecimArgs a)
 {
     // the VALU pieces' stage buffers, or (matrix-core workgroups of the long cascades) the four waves' LDS-DMA rings
     constexpr int LDSDW = mf_dma_applies(L) && mf_wave_ring(NG) > DecimLds<L, 2, PACK16>::dwords ? mf_wave_ring(NG) : DecimLds<L, 2, PACK16>::dwords; // (4 waves x ring bytes / 4)
@@ -737,6 +738,11 @@ template <int L> hipError_t launch_mf(bool pack16, const DecimArgs &a, hipStream
             else launch_mf2<L, 3, false>(pack16, a, grid, block, stream);
             return hipGetLastError();
         }
+        if (a.mf_ring == 2) { // (experiment: two waves per SIMD, 72 KiB of ring per workgroup, two workgroups per CU)
+            if (a.frame_mode) launch_mf2<L, 2, true>(pack16, a, grid, block, stream);
+            else launch_mf2<L, 2, false>(pack16, a, grid, block, stream);
+            return hipGetLastError();
+        }
     }
     if (a.frame_mode) launch_mf2<L, 4, true>(pack16, a, grid, block, stream);
     else launch_mf2<L, 4, false>(pack16, a, grid, block, stream);
@@ -781,7 +787,8 @@ bool plan_decimate_mfma(int log2decim, int fcpos, size_t n_used, int nstreams, s
             // from the wave count so that the VALU tail stays short.  Banks too big for that (spans beyond the limit of
             // the planner): spans of 32 Ki samples, the waves are dealt dynamically over many rounds.
             const size_t SL = 32768 > 8 * W ? 32768 : 8 * W;
-            const size_t wps1 = waves1 / (size_t)nstreams;
+            // (a->mf_ring == 2, decimate16 only: the two-waves-per-SIMD experiment -- 62 workgroups per XCD, spans half as long)
+            const size_t wps1 = (mf_dma_applies(log2decim) && a->mf_ring == 2 ? 2 * waves1 : waves1) / (size_t)nstreams;
             S = SL;
             if (wps1 >= 1) {
                 size_t S1 = n / (8 * wps1) / W * W;

@@ -216,7 +216,7 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
     else if (k == "rx_fused" && v == "overlap") c->opt.rx_fused = 3;
     else if (k == "rx_direct" && isnum && num <= 1) c->opt.rx_direct = (int)num;
     else if (k == "rx_window" && isnum && num <= 8) c->opt.rx_window = (int)num;
-    else if (k == "mfma_ring" && isnum && (num == 3 || num == 4)) c->opt.mfma_ring = (int)num;
+    else if (k == "mfma_ring" && isnum && num >= 2 && num <= 4) c->opt.mfma_ring = (int)num;
     else if (k == "tx_overlap" && isnum && num <= 1) c->opt.tx_overlap = (int)num;
     else if (k == "fec_stagger" && isnum && num <= 64) c->opt.fec_stagger = (int)num;
     else if (k == "fec_stagger_mod" && isnum && num <= 116) c->opt.fec_stagger_mod = (int)num;
@@ -471,10 +471,10 @@ int decimate_device(sdrhip_decimators *d, int log2decim, int fcpos, unsigned *sa
     bool use_mfma = false;
     // (frame mode on the matrix cores: the waves' store offsets are 32 bits with the top two reserved, decim_mfma.hip)
     const bool mfma_frames = env.rx_direct && out_stride * 4 < 0x3fffffffu;
+    a.mf_ring = coresident ? 3 : env.mfma_ring; // (the planner reads it: ring 2 = two waves per SIMD)
     if ((!frame_mode || mfma_frames) && env.decim_path != DECIM_PATH_VALU && (env.decim_path == DECIM_PATH_MFMA || a.n_used * (size_t)d->nstreams >= mfma_min_samples(env, (int)L)))
         use_mfma = plan_decimate_mfma((int)L, fcpos, a.n_used, d->nstreams, env.mfma_span, c->n_cu, &a);
     a.mf_dump = c->decim_dump;
-    a.mf_ring = coresident ? 3 : env.mfma_ring;
     a.mf_prio = coresident ? 1 : 0;
     hipError_t e;
     {
@@ -524,6 +524,8 @@ bool decimate_mfma_applies(const sdrhip_decimators *d, int log2decim, int fcpos,
     const size_t n_used = (n_in >> log2decim) << log2decim;
     if (env.decim_path == DECIM_PATH_VALU || (env.decim_path != DECIM_PATH_MFMA && n_used * (size_t)d->nstreams < mfma_min_samples(env, log2decim))) return false;
     DecimArgs tmp;
+    memset(&tmp, 0, sizeof(tmp));
+    tmp.mf_ring = env.mfma_ring;
     return plan_decimate_mfma(log2decim, fcpos, n_used, d->nstreams, env.mfma_span, d->ctx->n_cu, &tmp);
 }
 } // namespace sdrhip

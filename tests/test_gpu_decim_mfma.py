@@ -140,3 +140,38 @@ def test_mfma_rx_pipe_frames(ctx, oracle, mfma_path, nb_fec):
         for f in range(5):
             assert np.array_equal(got[f, :128], exp[f]), (span, f)
             assert np.array_equal(got[f, 128:], oracle.frame_encode(exp[f], nb_fec)), (span, f)
+
+
+def test_mfma_ring_depths_agree(ctx, oracle, mfma_path):
+    """decimate16 on the LDS-DMA ring at every depth the library has -- 4 groups (the product: one wave per SIMD), 3 (beside another kernel),
+    2 (the two-waves-per-SIMD experiment of round 6: spans half as long, a whole group issued per 8 steps) -- : the same bytes, through the
+    decimator alone (stream 0 against the oracle) and through the Rx pipe's frame-layout stores (two ragged calls)."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    mfma_path(0)
+    S, n = 8, (1 << 23) + 4 * 1111
+    x = np.stack([signals.noise(n, 900 + s) for s in range(S)])
+    xd = torch.from_numpy(x).cuda()
+    exp0, _ = oracle.decimators(0).decimate(4, 2, 16, x[0])
+    outs, frames, plans = [], [], []
+    try:
+        for ring in (4, 3, 2):
+            ctx.set_option("mfma_ring", ring)
+            d = sd.Decimators(ctx, S, 0)
+            y, _ = d.decimate(4, 2, 16, xd)
+            plans.append(d.last_plan())
+            outs.append(y.clone())
+            rx = sd.RxPipe(ctx, S, log2decim=4, nb_fec=32)
+            cut = (n // 3) & ~3
+            frames.append(torch.cat([rx.process(xd[:, :cut], 1, 2), rx.process(xd[:, cut:], 3, 4)], dim=1).clone())
+        ctx.synchronize()
+    finally:
+        ctx.set_option("mfma_ring", 4)
+    assert all(p["path"] == "mfma" for p in plans), plans
+    assert plans[2]["wps"] > plans[0]["wps"], plans  # (ring 2 really planned two waves per SIMD)
+    assert np.array_equal(outs[0][0].cpu().numpy(), exp0)
+    for k in (1, 2):
+        assert torch.equal(outs[k], outs[0]), k
+        assert torch.equal(frames[k], frames[0]), k
