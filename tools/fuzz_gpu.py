@@ -55,7 +55,7 @@ while time.time() - t0 < budget and (max_it == 0 or it < max_it):
     ctx.set_option("decim_path", str(rs.choice(["auto", "valu", "mfma", "mfma"])))
     ctx.set_option("mfma_span", 1024 * int(rs.choice([1, 1, 2, 3, 5, 16])))
     ctx.set_option("rx_fused", int(rs.choice([0, 1, 3])))  # pipelined Rx: the waiting encode in its own launch / inside the decimator's / on the second stream
-    ctx.set_option("mfma_ring", int(rs.choice([3, 4])))      # LDS-DMA ring depth of the decimate16 matrix-core kernel
+    ctx.set_option("mfma_ring", int(rs.choice([2, 3, 4, 4])))  # LDS-DMA ring depth of the decimate16 matrix-core kernel (2 = two waves per SIMD)
     ctx.set_option("tx_overlap", int(rs.randint(0, 2)))      # pipelined Tx: decode on the second stream / on the first
     ctx.set_option("rx_direct", int(rs.randint(0, 2)))       # matrix-core decimator inside the Rx pipe: frame-layout stores / stream order + framing pass
     ctx.set_option("enc_path", str(rs.choice(["fft", "fft", "karatsuba"])))  # CM256 128 + R encoder and the syndrome decoder's walk
