@@ -116,3 +116,53 @@ def test_device_call_too_short_for_any_output_needs_no_output_buffer(ctx):
     x = torch.zeros((2, 4, 2), dtype=torch.int16, device="cuda")
     y, ss = d.decimate(4, 2, 16, x[:, :3])
     assert tuple(y.shape) == (2, 0, 2) and ss == 16
+
+
+def test_create_use_destroy_cycles_do_not_leak():
+    """A daemon reconfigures for months: 120 cycles of context + every handle kind, each used once (device buffers, pinned staging, streams,
+    events, the asynchronous rings), then closed.  Device memory and the process's resident set must come back."""
+    import gc
+    import resource
+
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    x = np.zeros((2, 70000, 2), np.int16)
+    x[:, :, 0] = np.arange(70000) % 251
+
+    def cycle(i):
+        c = sd.Context(0)
+        d = sd.Decimators(c, 2, i & 1)
+        y, _ = d.decimate(4, 2, 16, x)
+        u = sd.Interpolators(c, 2)
+        z = u.interpolate(2, y)
+        rx = sd.RxPipe(c, 2, log2decim=1 + i % 4, nb_fec=8 * (i % 5), pipelined=bool(i & 2))
+        fr = rx.process(x, 1, 2)
+        tx = sd.TxPipe(c, 2, 1 + i % 3)
+        if fr.shape[1]:
+            tx.process(np.ascontiguousarray(fr[:, :, :128]))
+        ts = sd.TestSource(c, 2)
+        ts.read(4096)
+        cm = sd.CM256(c)
+        assert cm.isInitialized()
+        c.synchronize()
+        for obj in (ts, tx, rx, u, d):
+            obj.close()
+        c.close()
+        return z.shape
+
+    for i in range(8):  # allocator pools, code objects, hipBLAS-free first-use costs
+        cycle(i)
+    gc.collect()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    for i in range(120):
+        cycle(i)
+    gc.collect()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    rss1 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert free0 - free1 < 64 << 20, "device memory leaked: %.1f MiB over 120 cycles" % ((free0 - free1) / 2**20)
+    assert rss1 - rss0 < 96 << 10, "host memory grew by %.1f MiB over 120 cycles (ru_maxrss)" % ((rss1 - rss0) / 1024)
