@@ -79,7 +79,7 @@ int sdrhip_ctx_synchronize(sdrhip_ctx *ctx);
  * runs), "rx_direct" = 1 | 0 (Rx pipe on the matrix-core decimator: frame-layout stores, the default, or stream order + framing pass),
  * "enc_path" = fft | karatsuba (CM256 128 + R encoder and the batched decoder's walk: additive FFT for R <= 32, the default, or the
  * Karatsuba XOR-convolution walk), "enc_min_rows" = 1..32 (fewest recovery blocks the FFT encoder serves; below: the generic matrix
- * kernel), "mfma_ring" = 4 | 3 | 2 (2: the two-waves-per-SIMD experiment, slower), "tx_overlap" = 1 | 0 (pipelined Tx: decode on the second stream), "dec_path" = syndrome | dense, "dec_plan" =
+ * kernel), "enc_units" = frame | half (the FFT encoder's workgroup: a frame, the default, or one column half of a frame -- an experiment, no faster), "mfma_ring" = 4 | 3 | 2 (2: the two-waves-per-SIMD experiment, slower), "tx_overlap" = 1 | 0 (pipelined Tx: decode on the second stream), "dec_path" = syndrome | dense, "dec_plan" =
  * fused | kernel (batched decode with dec_max_rows <= 32 on the FFT decoder: each frame's plan is made by the decoder's own
  * workgroup, the default, or by the planning kernel in a launch of its own), "rx_window" = 0 | 1..8 (frame window of the Rx pipe in
  * calls; 0 = the default: 2, pipelined pipes 4), "fec_stagger" / "fec_stagger_mod" (experiment: staggered start of the FFT encoder's /

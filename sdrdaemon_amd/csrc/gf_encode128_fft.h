@@ -253,7 +253,8 @@ template <int HF, class MID, class POST> __device__ __forceinline__ void fft_row
 // place, fused framing copy) is gf_encode128_wg's, block for block.
 // (HF = the wave's block half as a template parameter: the two halves run different code, see fft_rows16; the dispatch sits at the
 // very top -- gf_encode128_fft_wg -- so that no register value has to survive a join of the two variants)
-template <int HF> __device__ __forceinline__ void gf_encode128_fft_wave(const Enc128Args &a, int fi, unsigned char *ldsraw, int ch)
+// (xslot: which of the workgroup's exchange areas the column half uses -- ch in a whole-frame workgroup, 0 in a half-frame one)
+template <int HF> __device__ __forceinline__ void gf_encode128_fft_wave(const Enc128Args &a, int fi, unsigned char *ldsraw, int ch, int xslot)
 {
     constexpr int hf = HF;
     const unsigned la = lds_addr(ldsraw);
@@ -302,7 +303,7 @@ template <int HF> __device__ __forceinline__ void gf_encode128_fft_wave(const En
             sbase = a.lin + (size_t)s * a.lin_stride;
         }
     }
-    unsigned *const xch0 = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES) + ch * FFT_XCH_DWORDS; // [i][lane], i < 32; parity at [32], [33]
+    unsigned *const xch0 = reinterpret_cast<unsigned *>(ldsraw + FFT_TAB_BYTES) + xslot * FFT_XCH_DWORDS; // [i][lane], i < 32; parity at [32], [33]
 
     // ONE load sequence for both sources (descriptor and block pitch are picked once, uniformly): two sequences that define the
     // same 64 registers met in a join the register allocator answered with a few hundred moves and spills
@@ -393,7 +394,36 @@ __device__ __forceinline__ void gf_encode128_fft_wg(const Enc128Args &a, int fi,
     fec_stagger_sleep(fi, a.stagger, a.stagger_div);
     FFT_STAMP(1);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wv >> 1) gf_encode128_fft_wave<1>(a, fi, ldsraw, wv & 1);
-    else gf_encode128_fft_wave<0>(a, fi, ldsraw, wv & 1);
+    if (wv >> 1) gf_encode128_fft_wave<1>(a, fi, ldsraw, wv & 1, wv & 1);
+    else gf_encode128_fft_wave<0>(a, fi, ldsraw, wv & 1, wv & 1);
+}
+
+// Half-frame workgroups (round 6, last session; context option enc_units = half): the two column halves of a frame share nothing but the
+// tables, so a workgroup can be ONE column half -- two waves (block halves), 128 threads, 6 KB of tables + one exchange area.  The launch
+// lasts as long as the CU with the most work (profiles/r06_enc_count_scan.txt: ~10 us + 5.1 us x ceil(frames / 256)); in half frames the
+// Rx step's 1040 frames are 8.1 -> 9 units on the fullest CU = 4.5 frames instead of 5.
+constexpr int ENC128_FFT_HALF_LDS = FFT_TAB_BYTES + FFT_XCH_DWORDS * 4;
+__device__ __forceinline__ void fft_fill_tables_half(const Enc128Args &a, unsigned char *ldsraw)
+{
+    static_assert(FFT_NTAB * 2 == 3 * 128, "three loads per thread");
+    const unsigned tid = threadIdx.x;
+    const uint4_t *src = reinterpret_cast<const uint4_t *>(a.fft_tables);
+    uint4_t f0, f1, f2;
+    asm volatile("global_load_dwordx4 %0, %3, off\n\tglobal_load_dwordx4 %1, %4, off\n\tglobal_load_dwordx4 %2, %5, off\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(f0), "=&v"(f1), "=&v"(f2) : "v"(src + tid), "v"(src + 128u + tid), "v"(src + 256u + tid) : "memory");
+    uint4_t *lt = reinterpret_cast<uint4_t *>(ldsraw);
+    lt[tid] = f0;
+    lt[128u + tid] = f1;
+    lt[256u + tid] = f2;
+    __syncthreads();
+}
+__device__ __forceinline__ void gf_encode128_fft_half_wg(const Enc128Args &a, int ui, unsigned char *ldsraw)
+{
+    const int fi = ui >> 1, ch = ui & 1;
+    fft_fill_tables_half(a, ldsraw);
+    fec_stagger_sleep(fi, a.stagger, a.stagger_div);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wv) gf_encode128_fft_wave<1>(a, fi, ldsraw, ch, 0);
+    else gf_encode128_fft_wave<0>(a, fi, ldsraw, ch, 0);
 }
 __device__ __forceinline__ void gf_encode128_fft_unit(const Enc128Args &a, int fi, unsigned char *ldsraw) { gf_encode128_fft_wg(a, fi, ldsraw); }

@@ -161,6 +161,13 @@ __global__ __launch_bounds__(GF_NT, FFT_WAVES_PER_EU) void gf_encode128_fft_kern
     gf_encode128_fft_unit(a, (int)blockIdx.x, ldsraw);
 }
 
+// ... in half-frame workgroups (Enc128Args::half_units): grid = 2 x frames, 128 threads
+__global__ __launch_bounds__(128, FFT_WAVES_PER_EU) void gf_encode128_fft_half_kernel(Enc128Args a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char ldsraw[ENC128_FFT_HALF_LDS];
+    gf_encode128_fft_half_wg(a, (int)blockIdx.x, ldsraw);
+}
+
 // The Rx pipe's last launch: the encoder's workgroups and, behind them, K2's (the frames left open at either end of the call,
 // meta blocks, headers).  One launch instead of two: K2 used to run first because the encoder reads what K2 writes (block 0 of
 // the frames the call starts, the tail of the frame the call completes); now the encoder derives / fetches both itself
@@ -792,7 +799,8 @@ extern "C" int sdrhip_debug_fft_stamps(unsigned long long *dst) { return (int)hi
 hipError_t launch_gf_encode128(const Enc128Args &a, hipStream_t stream)
 {
     if (a.nlist <= 0 || a.rows <= 0) return hipSuccess;
-    if (a.use_fft && a.fft_tables && a.rows <= FFT_MAX_ROWS) hipLaunchKernelGGL(gf_encode128_fft_kernel, dim3(a.nlist), dim3(GF_NT), 0, stream, a);
+    if (a.use_fft && a.fft_tables && a.rows <= FFT_MAX_ROWS && a.half_units) hipLaunchKernelGGL(gf_encode128_fft_half_kernel, dim3(2 * a.nlist), dim3(128), 0, stream, a);
+    else if (a.use_fft && a.fft_tables && a.rows <= FFT_MAX_ROWS) hipLaunchKernelGGL(gf_encode128_fft_kernel, dim3(a.nlist), dim3(GF_NT), 0, stream, a);
     else hipLaunchKernelGGL(gf_encode128_kernel, dim3(2 * a.nlist), dim3(GF_NT), 0, stream, a);
     return hipGetLastError();
 }

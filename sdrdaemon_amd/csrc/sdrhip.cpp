@@ -120,7 +120,7 @@ extern "C" int sdrhip_ctx_create(int device, void *hip_stream, sdrhip_ctx **out)
         // sdrhip_ctx_set_option()
         static const char *const keys[][2] = {{"SDRHIP_DECIM_PATH", "decim_path"}, {"SDRHIP_MFMA_SPAN", "mfma_span"}, {"SDRHIP_MFMA_MIN", "mfma_min"},
                                               {"SDRHIP_INTERP_PATH", "interp_path"}, {"SDRHIP_INTERP_SPAN", "interp_span"}, {"SDRHIP_RX_FUSED", "rx_fused"}, {"SDRHIP_RX_DIRECT", "rx_direct"},
-                                              {"SDRHIP_DEC_PATH", "dec_path"}, {"SDRHIP_ENC_PATH", "enc_path"}, {"SDRHIP_ENC_MIN_ROWS", "enc_min_rows"}, {"SDRHIP_MFMA_RING", "mfma_ring"}, {"SDRHIP_TX_OVERLAP", "tx_overlap"}, {"SDRHIP_RX_WINDOW", "rx_window"}, {"SDRHIP_FEC_STAGGER", "fec_stagger"}, {"SDRHIP_FEC_STAGGER_MOD", "fec_stagger_mod"}, {"SDRHIP_DEC_PLAN", "dec_plan"}, {"SDRHIP_TX_GATHER", "tx_gather"}};
+                                              {"SDRHIP_DEC_PATH", "dec_path"}, {"SDRHIP_ENC_PATH", "enc_path"}, {"SDRHIP_ENC_MIN_ROWS", "enc_min_rows"}, {"SDRHIP_MFMA_RING", "mfma_ring"}, {"SDRHIP_TX_OVERLAP", "tx_overlap"}, {"SDRHIP_RX_WINDOW", "rx_window"}, {"SDRHIP_FEC_STAGGER", "fec_stagger"}, {"SDRHIP_FEC_STAGGER_MOD", "fec_stagger_mod"}, {"SDRHIP_DEC_PLAN", "dec_plan"}, {"SDRHIP_TX_GATHER", "tx_gather"}, {"SDRHIP_ENC_UNITS", "enc_units"}};
         for (size_t i = 0; i < sizeof(keys) / sizeof(keys[0]); ++i)
             if (const char *v = getenv(keys[i][0])) (void)sdrhip_ctx_set_option(c, keys[i][1], v);
     }
@@ -227,6 +227,7 @@ extern "C" int sdrhip_ctx_set_option(sdrhip_ctx *c, const char *key, const char 
         else return fail(SDRHIP_EINVAL, "ctx_set_option: dec_plan must be fused or kernel");
     }
     else if (k == "enc_min_rows" && isnum && num >= 1 && num <= 32) c->opt.enc_min_rows = (int)num;
+    else if (k == "enc_units" && (v == "frame" || v == "half")) c->opt.enc_half = v == "half";
     else if (k == "enc_path") {
         if (v == "fft") c->opt.enc_fft = 1;
         else if (v == "karatsuba") c->opt.enc_fft = 0;

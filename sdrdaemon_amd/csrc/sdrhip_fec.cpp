@@ -23,6 +23,7 @@ int fec_encode128_launch(sdrhip_ctx *c, const Enc128Args &k, hipStream_t on)
         KTimer kt(c, SDRHIP_K_FEC_ENCODE, on);
         Enc128Args ks = k;
         ks.stagger = c->opt.fec_stagger; ks.stagger_div = c->opt.fec_stagger_mod ? -c->opt.fec_stagger_mod : c->n_cu;
+        ks.half_units = c->opt.enc_half;
         e = launch_gf_encode128(ks, on ? on : c->stream);
     }
     if (e != hipSuccess) return fail(SDRHIP_EDEVICE, "fec encode launch: %s", hipGetErrorString(e));
@@ -45,6 +46,7 @@ int fec_encode_device(sdrhip_ctx *c, const uint8_t *frames, size_t frame_bytes, 
         k.frame_list = frame_list_dev; k.nlist = frame_list_dev ? ngroups * GF_FRAMES_PER_GROUP : (int)nframes;
         if (lin) { k.lin = lin->lin; k.lin_stride = lin->stride; k.lin_cap = lin->cap; k.lin_first = lin->first; k.lin_pending = lin->pending; }
         k.stagger = c->opt.fec_stagger; k.stagger_div = c->opt.fec_stagger_mod ? -c->opt.fec_stagger_mod : c->n_cu;
+        k.half_units = c->opt.enc_half;
         {
             KTimer kt(c, SDRHIP_K_FEC_ENCODE);
             e = launch_gf_encode128(k, c->stream);

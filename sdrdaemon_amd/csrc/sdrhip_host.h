@@ -147,6 +147,7 @@ struct CtxOptions {
     int rx_window = 0;                     // frame window of the Rx pipe in calls (1..8); 0 = the default: 2, pipelined pipes 4 (sdrhip_rx_process)
     int tx_overlap = 1;                    // pipelined Tx pipe: 1 = decode of this batch on the second stream beside the interpolator of the previous one, 0 = one stream
     int enc_fft = 1;                       // structured 128-original encoder, rows <= 32: additive FFT (1) or the Karatsuba XOR-convolution walk (0)
+    int enc_half = 0;                      // FFT encoder in half-frame workgroups (enc_units = half): finer units for the CUs, 128 threads each
     int enc_min_rows = 1;                  // ... the FFT from this many recovery blocks on (the generic matrix kernel below)
     int fec_stagger_mod = 0;               // 0: phase = resident round (workgroup / CUs); 1..16: phase = workgroup mod m; 100 + m: arrival rank on the CU mod m (experiment)
     int fec_stagger = 0;                   // staggered start of the FFT encoder's / decoder's workgroups, units of 1024 clocks per resident round (0 = off)

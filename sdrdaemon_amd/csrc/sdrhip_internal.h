@@ -279,6 +279,7 @@ struct Enc128Args {
     // its loads (stagger_div = the number of CUs: the i-th workgroup a CU receives), so that the co-resident workgroups of a CU are
     // in different phases.  0 = off.
     int stagger, stagger_div;
+    int half_units;                 // 1: the FFT encoder runs in half-frame workgroups (gf_encode128_fft_half_kernel; context option enc_units)
 };
 // the sleep in front of a workgroup's loads (Enc128Args::stagger, DecodeBuffers::stagger)
 #if defined(__HIPCC__)

@@ -423,3 +423,44 @@ def test_strict_mode_leaves_the_reference_s_holes(ctx, oracle, dec_path):
     finally:
         ctx.set_option("dec_strict", 0)
         ctx.set_option("dec_path", "syndrome")
+
+
+def test_half_frame_workgroups_equal_whole_frame_workgroups(ctx, oracle):
+    """enc_units = half (the FFT encoder in workgroups of one column half: two waves) against the default and the oracle: every row count the
+    FFT path serves, a frame count that is not a multiple of anything, and the Rx pipe's three ways into the encoder -- frames in memory
+    (rx_direct), the fused framing copy from the stream-order buffer with a frame straddling the calls (rx_direct = 0), the pipelined pipe."""
+    import torch
+
+    import sdrdaemon_amd as sd
+
+    F = 37
+    x = signals.noise(F * 16129, 4242)
+    try:
+        for R in (1, 5, 16, 17, 31, 32):
+            frames = oracle.framer(nb_fec_blocks=R).write(x)
+            frames[:, :, 3] = 0
+            ctx.set_option("enc_units", "frame")
+            a = sd.fec_encode_frames(ctx, frames, R)
+            ctx.set_option("enc_units", "half")
+            b = sd.fec_encode_frames(ctx, frames, R)
+            assert np.array_equal(a, b), R
+            for f in (0, 17, F - 1):
+                assert np.array_equal(b[f], oracle.frame_encode(frames[f], R)), (R, f)
+        S, n = 3, (1 << 22) + 4 * 777
+        xs = torch.from_numpy(np.stack([signals.noise(n, 60 + s) for s in range(S)])).cuda()
+        cut = (n // 3 + 40) & ~3
+        for direct, pipelined in ((1, False), (0, False), (1, True), (0, True)):
+            res = []
+            for units in ("frame", "half"):
+                ctx.set_option("enc_units", units)
+                ctx.set_option("rx_direct", direct)
+                rx = sd.RxPipe(ctx, S, log2decim=4, nb_fec=32, pipelined=pipelined)
+                parts = [rx.process(xs[:, :cut], 1, 2), rx.process(xs[:, cut:], 3, 4)]
+                if pipelined:
+                    parts.append(torch.from_numpy(rx.flush()).cuda())
+                res.append(torch.cat([p for p in parts if p.shape[1]], dim=1).clone())
+            ctx.synchronize()
+            assert torch.equal(res[0], res[1]), (direct, pipelined)
+    finally:
+        ctx.set_option("enc_units", "frame")
+        ctx.set_option("rx_direct", 1)

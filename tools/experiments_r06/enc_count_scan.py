@@ -26,6 +26,9 @@ def timed(fn, reps=40):
     ms, n = ctx.kernel_timing_read(K_FEC_ENCODE)
     ctx.kernel_timing(False)
     return ms / max(n, 1)
+UNITS = os.environ.get("ENC_UNITS", "frame")  # frame | half (context option enc_units)
+ctx.set_option("enc_units", UNITS)
+print("enc_units =", UNITS)
 for rnd in range(2):
     for F in (256, 512, 768, 1024, 1040, 1152, 1280, 1296, 1536, 2048, 2560, 4096):
         fr = allf[:F]
