@@ -64,6 +64,7 @@ while time.time() - t0 < budget and (max_it == 0 or it < max_it):
     ctx.set_option("dec_plan", str(rs.choice(["fused", "fused", "kernel"])))    # dec_max_rows <= 32 on the FFT decoder: the plan inside the decoder's launch / gf_decode_plan_kernel in front
     ctx.set_option("interp_path", str(rs.choice(["wave", "wave", "valu"])))     # K5w (default) / K5
     ctx.set_option("interp_span", int(rs.choice([0, 0, 128, 256, 640, 2048])))  # segment length in inputs (0 = the planner's)
+    ctx.set_option("enc_units", str(rs.choice(["frame", "frame", "half"])))       # FFT encoder: a workgroup per frame / per column half of a frame
     if what == "decim":
         S = int(rs.randint(1, 4))
         bias = int(rs.randint(0, 2))
